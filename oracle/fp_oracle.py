@@ -1,0 +1,158 @@
+"""ctypes binding of the CPU oracle (oracle/fp_oracle.c).  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module.  Element arrays are numpy uint64 arrays of shape (count, n64):
+little-endian 64-bit words, the reference's `as_words()` layout
+(src/semiring/crypto_bigint_uint.rs:65-68).
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libfp_oracle.so")
+
+MUL, SQR, ADD, SUB, NEG, TO_MONT, FROM_MONT, MUL_BOXED = range(8)
+
+
+def build(force=False):
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(
+        os.path.join(_HERE, "fp_oracle.c")
+    ):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libfp_oracle.so"])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        _lib = ctypes.CDLL(_SO)
+        _lib.fpo_mod_neg_inv.restype = ctypes.c_uint64
+        _lib.fpo_mod_neg_inv.argtypes = [ctypes.c_uint64]
+        _lib.fpo_max_threads.restype = ctypes.c_int
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p) if a is not None else None
+
+
+def _arr(x, n64=None):
+    a = np.ascontiguousarray(x, dtype=np.uint64)
+    if n64 is not None:
+        a = a.reshape(-1, n64)
+    return a
+
+
+def int_to_words(v, n64):
+    return np.array([(v >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(n64)], dtype=np.uint64)
+
+
+def words_to_int(w):
+    return sum(int(x) << (64 * i) for i, x in enumerate(np.asarray(w).reshape(-1)))
+
+
+def ints_to_array(vals, n64):
+    out = np.zeros((len(vals), n64), dtype=np.uint64)
+    for i, v in enumerate(vals):
+        out[i] = int_to_words(v, n64)
+    return out
+
+
+def array_to_ints(a):
+    a = np.asarray(a)
+    return [words_to_int(r) for r in a]
+
+
+class Oracle:
+    """The reference's scalar ops looped over element arrays, for one modulus."""
+
+    def __init__(self, modulus: int, n64: int):
+        self.n64 = n64
+        self.p = modulus
+        self.mod = int_to_words(modulus, n64)
+        inv = ctypes.c_uint64()
+        one = np.zeros(n64, dtype=np.uint64)
+        r2 = np.zeros(n64, dtype=np.uint64)
+        rc = lib().fpo_params(_p(self.mod), ctypes.c_size_t(n64), ctypes.byref(inv), _p(one), _p(r2))
+        if rc != 0:
+            raise ValueError("InvalidModulus")
+        self.mod_neg_inv = inv.value
+        self.one = one
+        self.r2 = r2
+
+    def batch(self, op, a, b=None, threads=1):
+        a = _arr(a, self.n64)
+        b = _arr(b, self.n64) if b is not None else None
+        out = np.empty_like(a)
+        rc = lib().fpo_batch_op(
+            ctypes.c_int(op), _p(self.mod), ctypes.c_size_t(self.n64), _p(a), _p(b), _p(out),
+            ctypes.c_size_t(a.shape[0]), ctypes.c_int(threads))
+        assert rc == 0
+        return out
+
+    def mul(self, a, b, threads=1): return self.batch(MUL, a, b, threads)
+    def mul_boxed(self, a, b, threads=1): return self.batch(MUL_BOXED, a, b, threads)
+    def sqr(self, a, threads=1): return self.batch(SQR, a, None, threads)
+    def add(self, a, b, threads=1): return self.batch(ADD, a, b, threads)
+    def sub(self, a, b, threads=1): return self.batch(SUB, a, b, threads)
+    def neg(self, a, threads=1): return self.batch(NEG, a, None, threads)
+    def to_mont(self, a, threads=1): return self.batch(TO_MONT, a, None, threads)
+    def from_mont(self, a, threads=1): return self.batch(FROM_MONT, a, None, threads)
+
+    def batch_inv(self, x, threads=1):
+        x = _arr(x, self.n64)
+        out = np.empty_like(x)
+        flags = np.zeros(x.shape[0], dtype=np.uint8)
+        rc = lib().fpo_batch_inv(_p(self.mod), ctypes.c_size_t(self.n64), _p(x), _p(out), _p(flags),
+                                 ctypes.c_size_t(x.shape[0]), ctypes.c_int(threads))
+        assert rc == 0
+        return out, flags
+
+    def sum(self, v):
+        v = _arr(v, self.n64)
+        out = np.zeros(self.n64, dtype=np.uint64)
+        lib().fpo_sum(_p(self.mod), ctypes.c_size_t(self.n64), _p(v), ctypes.c_size_t(v.shape[0]), _p(out))
+        return out
+
+    def product(self, v):
+        v = _arr(v, self.n64)
+        out = np.zeros(self.n64, dtype=np.uint64)
+        lib().fpo_product(_p(self.mod), ctypes.c_size_t(self.n64), _p(v), ctypes.c_size_t(v.shape[0]), _p(out))
+        return out
+
+    def matvec(self, A, rows, cols, x, threads=1):
+        A = _arr(A, self.n64)
+        x = _arr(x, self.n64)
+        assert A.shape[0] == rows * cols and x.shape[0] == cols
+        y = np.zeros((rows, self.n64), dtype=np.uint64)
+        lib().fpo_matvec(_p(self.mod), ctypes.c_size_t(self.n64), _p(A), ctypes.c_size_t(rows),
+                         ctypes.c_size_t(cols), _p(x), _p(y), ctypes.c_int(threads))
+        return y
+
+    def matmul(self, A, B, m, k, n, threads=1):
+        A = _arr(A, self.n64)
+        B = _arr(B, self.n64)
+        assert A.shape[0] == m * k and B.shape[0] == k * n
+        C = np.zeros((m * n, self.n64), dtype=np.uint64)
+        lib().fpo_matmul(_p(self.mod), ctypes.c_size_t(self.n64), _p(A), _p(B), _p(C),
+                         ctypes.c_size_t(m), ctypes.c_size_t(k), ctypes.c_size_t(n), ctypes.c_int(threads))
+        return C
+
+    def bench_mul_assign(self, elem, iters):
+        elem = _arr(elem).reshape(-1)
+        out = np.zeros(self.n64, dtype=np.uint64)
+        lib().fpo_bench_mul_assign(_p(self.mod), ctypes.c_size_t(self.n64), _p(elem),
+                                   ctypes.c_size_t(iters), _p(out))
+        return out
+
+
+def max_threads():
+    return lib().fpo_max_threads()
