@@ -1,0 +1,89 @@
+"""ctypes loader for libfpgpu.so (the C ABI declared in include/fpgpu.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` / ``make -C
+crypto_primitives_amd``.  There is no fallback: if the shared object is missing
+or no MI355X is visible, calls fail loudly.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfpgpu.so")
+
+OK, ERR_INVALID_MODULUS, ERR_UNSUPPORTED, ERR_SHAPE, ERR_HIP, ERR_NO_DEVICE = range(6)
+
+_c = ctypes
+_vp, _sz, _u32, _u64, _int = _c.c_void_p, _c.c_size_t, _c.c_uint32, _c.c_uint64, _c.c_int
+
+# name -> (restype, argtypes); mirrors include/fpgpu.h one to one
+SIGNATURES = {
+    "fpgpu_ctx_create": (_int, [_vp, _u32, _c.POINTER(_vp)]),
+    "fpgpu_ctx_destroy": (None, [_vp]),
+    "fpgpu_ctx_n64": (_u32, [_vp]),
+    "fpgpu_ctx_params": (_int, [_vp, _vp, _vp, _vp, _c.POINTER(_u64)]),
+    "fpgpu_mul_dev": (_int, [_vp, _vp, _vp, _vp, _sz, _vp]),
+    "fpgpu_sqr_dev": (_int, [_vp, _vp, _vp, _sz, _vp]),
+    "fpgpu_add_dev": (_int, [_vp, _vp, _vp, _vp, _sz, _vp]),
+    "fpgpu_sub_dev": (_int, [_vp, _vp, _vp, _vp, _sz, _vp]),
+    "fpgpu_neg_dev": (_int, [_vp, _vp, _vp, _sz, _vp]),
+    "fpgpu_to_mont_dev": (_int, [_vp, _vp, _vp, _sz, _vp]),
+    "fpgpu_from_mont_dev": (_int, [_vp, _vp, _vp, _sz, _vp]),
+    "fpgpu_mul_chain_dev": (_int, [_vp, _vp, _vp, _vp, _sz, _u32, _vp]),
+    "fpgpu_batch_inv_workspace_bytes": (_sz, [_vp, _sz]),
+    "fpgpu_batch_inv_dev": (_int, [_vp, _vp, _vp, _vp, _sz, _vp, _sz, _vp]),
+    "fpgpu_matvec_dev": (_int, [_vp, _vp, _sz, _sz, _vp, _vp, _vp]),
+    "fpgpu_matmul_dev": (_int, [_vp, _vp, _vp, _vp, _sz, _sz, _sz, _vp]),
+    "fpgpu_fill_random_dev": (_int, [_vp, _vp, _sz, _u64, _vp]),
+    "fpgpu_mul": (_int, [_vp, _vp, _vp, _vp, _sz]),
+    "fpgpu_sqr": (_int, [_vp, _vp, _vp, _sz]),
+    "fpgpu_add": (_int, [_vp, _vp, _vp, _vp, _sz]),
+    "fpgpu_sub": (_int, [_vp, _vp, _vp, _vp, _sz]),
+    "fpgpu_neg": (_int, [_vp, _vp, _vp, _sz]),
+    "fpgpu_to_mont": (_int, [_vp, _vp, _vp, _sz]),
+    "fpgpu_from_mont": (_int, [_vp, _vp, _vp, _sz]),
+    "fpgpu_mul_chain": (_int, [_vp, _vp, _vp, _vp, _sz, _u32]),
+    "fpgpu_batch_inv": (_int, [_vp, _vp, _vp, _vp, _sz]),
+    "fpgpu_matvec": (_int, [_vp, _vp, _sz, _sz, _vp, _vp]),
+    "fpgpu_matmul": (_int, [_vp, _vp, _vp, _vp, _sz, _sz, _sz]),
+    "fpgpu_last_error_string": (_c.c_char_p, []),
+    "fpgpu_device_count": (_int, []),
+    "fpgpu_version": (_c.c_char_p, []),
+}
+
+_lib = None
+
+
+def load():
+    """Load libfpgpu.so and declare every prototype.  Raises if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+        # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64.so.7.  If
+        # torch is going to be used beside this library (device tensors, RCCL), it must be
+        # loaded first so that our DT_NEEDED libamdhip64.so.7 binds to the copy torch
+        # already mapped; two runtimes in one process leave the second with no devices.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+class FpgpuError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"fpgpu error {code}: {msg}")
+        self.code = code
+
+
+def check(rc):
+    if rc != OK:
+        raise FpgpuError(rc, load().fpgpu_last_error_string().decode())

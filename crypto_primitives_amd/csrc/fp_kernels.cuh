@@ -1,0 +1,404 @@
+// fp_kernels.cuh -- gfx950 kernels over AoS element arrays (see include/fpgpu.h for
+// the layout contract).  Every kernel is HBM-streaming unless noted; DESIGN.md
+// lists algorithmic bytes per element and the roofline that bounds each.
+#pragma once
+#include "fp_device.cuh"
+
+namespace fpgpu {
+
+enum Op : int { OP_MUL = 0, OP_SQR = 1, OP_ADD = 2, OP_SUB = 3, OP_NEG = 4, OP_TO_MONT = 5, OP_FROM_MONT = 6 };
+
+constexpr int kBlock = 256;
+
+// ---- elementwise: out[i] = op(a[i], b[i]) ------------------------------------------
+// One element per lane per iteration, grid-stride.  Lane i of a wave reads its
+// whole 4N-byte element with 16-byte loads; a wave covers 64 consecutive elements
+// (2 KiB at N = 8), so every fetched 128-byte line is fully consumed by the wave
+// that touched it (measured 5.3 TB/s on the 2R+1W pattern, profiles/).
+template <int N, int OP>
+__global__ __launch_bounds__(kBlock) void k_elementwise(const uint32_t* __restrict__ a,
+                                                        const uint32_t* __restrict__ b,
+                                                        uint32_t* __restrict__ out, size_t n,
+                                                        const FpParams<N> P) {
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        uint32_t x[N], y[N], r[N];
+        load_elem<N>(x, a, i);
+        if constexpr (OP == OP_MUL || OP == OP_ADD || OP == OP_SUB) load_elem<N>(y, b, i);
+        if constexpr (OP == OP_MUL) mont_mul<N>(r, x, y, P);
+        else if constexpr (OP == OP_SQR) mont_mul<N>(r, x, x, P);
+        else if constexpr (OP == OP_ADD) mod_add<N>(r, x, y, P);
+        else if constexpr (OP == OP_SUB) mod_sub<N>(r, x, y, P);
+        else if constexpr (OP == OP_NEG) mod_neg<N>(r, x, P);
+        else if constexpr (OP == OP_TO_MONT) {
+            set_limbs<N>(y, P.r2);
+            mont_mul<N>(r, x, y, P);
+        } else if constexpr (OP == OP_FROM_MONT) mont_retrieve<N>(r, x, P);
+        store_elem<N>(out, i, r);
+    }
+}
+
+// ---- dependent multiply chain (VALU-bound; "Mul assign" bench shape) -----------
+template <int N>
+__global__ __launch_bounds__(kBlock) void k_mul_chain(const uint32_t* __restrict__ a,
+                                                      const uint32_t* __restrict__ b,
+                                                      uint32_t* __restrict__ out, size_t n, uint32_t iters,
+                                                      const FpParams<N> P) {
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        uint32_t acc[N], y[N], r[N];
+        load_elem<N>(acc, a, i);
+        load_elem<N>(y, b, i);
+        for (uint32_t it = 0; it < iters; it++) {
+            mont_mul<N>(r, acc, y, P);
+#pragma unroll
+            for (int l = 0; l < N; l++) acc[l] = r[l];
+        }
+        store_elem<N>(out, i, acc);
+    }
+}
+
+// ---- synthetic uniform field elements (SURVEY.md 8d generator) -----------------
+__device__ __forceinline__ uint64_t splitmix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+template <int N>
+__global__ __launch_bounds__(kBlock) void k_fill_random(uint32_t* __restrict__ out, size_t n, uint64_t seed,
+                                                        const FpParams<N> P) {
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        uint32_t x[N], d[N];
+#pragma unroll
+        for (int l = 0; l < N / 2; l++) {
+            uint64_t w = splitmix64(seed ^ (i * (N / 2) + l));
+            x[2 * l] = (uint32_t)w;
+            x[2 * l + 1] = (uint32_t)(w >> 32);
+        }
+        x[N - 2] &= P.top_mask;
+        x[N - 1] &= P.top_mask_hi;
+        uint32_t bo = sub_limbs_s<N>(d, x, P.m);
+#pragma unroll
+        for (int l = 0; l < N; l++) x[l] = bo ? x[l] : d[l];
+        store_elem<N>(out, i, x);
+    }
+}
+
+// ---- binary extended GCD inversion, one element per lane (vartime) -------------
+// Plain (non-Montgomery) inverse of a mod p for odd p; returns false when
+// gcd(a, p) != 1 (the reference's invert_odd_mod_vartime -> None).  Used only at
+// the top level of batch inversion and on its composite-modulus fallback path.
+template <int N>
+__device__ __forceinline__ void shr1(uint32_t (&a)[N], uint32_t top) {
+#pragma unroll
+    for (int i = 0; i < N - 1; i++) a[i] = (a[i] >> 1) | (a[i + 1] << 31);
+    a[N - 1] = (a[N - 1] >> 1) | (top << 31);
+}
+template <int N>
+__device__ __forceinline__ bool ge_limbs(const uint32_t (&a)[N], const uint32_t (&b)[N]) {
+    uint32_t d[N];
+    return sub_limbs<N>(d, a, b) == 0;
+}
+template <int N>
+__device__ __forceinline__ bool is_one(const uint32_t (&a)[N]) {
+    uint32_t z = a[0] ^ 1u;
+#pragma unroll
+    for (int i = 1; i < N; i++) z |= a[i];
+    return z == 0;
+}
+template <int N>
+__device__ __forceinline__ bool inv_gcd(uint32_t (&r)[N], const uint32_t (&a_in)[N], const FpParams<N>& P) {
+    uint32_t u[N], v[N], x1[N], x2[N], m[N], t[N];
+    set_limbs<N>(m, P.m);
+#pragma unroll
+    for (int i = 0; i < N; i++) { u[i] = a_in[i]; v[i] = m[i]; x1[i] = 0; x2[i] = 0; }
+    x1[0] = 1;
+    // reduce u below p (inputs are expected canonical; stay total)
+    for (int guard = 0; guard < 4 && ge_limbs<N>(u, m); guard++) sub_limbs<N>(u, u, m);
+    if (is_zero<N>(u)) return false;
+    if (is_one<N>(m)) return false;
+    // every subtraction is followed by a halving and u, v hold <= 32N bits each, so
+    // at most 2 * 2 * 32N + 2 single-action iterations are needed
+    for (int iter = 0; iter < 128 * N + 16; iter++) {
+        if (is_one<N>(u) || is_one<N>(v)) break;
+        if (is_zero<N>(u) || is_zero<N>(v)) return false;
+        if ((u[0] & 1u) == 0) {
+            shr1<N>(u, 0);
+            uint32_t c = 0;
+            if (x1[0] & 1u) c = add_limbs<N>(x1, x1, m);
+            shr1<N>(x1, c);
+        } else if ((v[0] & 1u) == 0) {
+            shr1<N>(v, 0);
+            uint32_t c = 0;
+            if (x2[0] & 1u) c = add_limbs<N>(x2, x2, m);
+            shr1<N>(x2, c);
+        } else if (ge_limbs<N>(u, v)) {
+            sub_limbs<N>(u, u, v);
+            if (sub_limbs<N>(t, x1, x2)) add_limbs<N>(t, t, m);
+#pragma unroll
+            for (int i = 0; i < N; i++) x1[i] = t[i];
+        } else {
+            sub_limbs<N>(v, v, u);
+            if (sub_limbs<N>(t, x2, x1)) add_limbs<N>(t, t, m);
+#pragma unroll
+            for (int i = 0; i < N; i++) x2[i] = t[i];
+        }
+    }
+    if (is_one<N>(u)) {
+#pragma unroll
+        for (int i = 0; i < N; i++) r[i] = x1[i];
+        return true;
+    }
+    if (is_one<N>(v)) {
+#pragma unroll
+        for (int i = 0; i < N; i++) r[i] = x2[i];
+        return true;
+    }
+    return false;
+}
+
+// Montgomery-form inverse exactly as MontyField::inv (crypto_bigint_monty.rs:223-237):
+// invert the representative, then two Montgomery multiplications by R^2.
+template <int N>
+__device__ __forceinline__ bool mont_inv_gcd(uint32_t (&r)[N], const uint32_t (&x)[N], const FpParams<N>& P) {
+    uint32_t inv[N], r2[N], t[N];
+    if (!inv_gcd<N>(inv, x, P)) return false;
+    set_limbs<N>(r2, P.r2);
+    mont_mul<N>(t, inv, r2, P);
+    mont_mul<N>(r, t, r2, P);
+    return true;
+}
+
+// ---- batch inversion: Montgomery's trick over interleaved chains -----------------
+// A "tile" is kBlock * C consecutive elements; lane t of the block owns the chain
+// {tile_base + t + kBlock * k : k < C}, so every global access is coalesced
+// (the product is commutative, any partition into chains is valid).
+//   k_binv_up:   prefix[e] = product of the chain's earlier elements (zeros taken
+//                as one), total[chain] = product of the whole chain.
+//   (recurse on the totals until few remain, invert those with the GCD kernel)
+//   k_binv_down: walks each chain backwards with the inverted total.
+// Chain index of element e at tile size T = kBlock*C: (e / T) * kBlock + (e % kBlock).
+template <int N, int C, bool LEVEL0>
+__global__ __launch_bounds__(kBlock) void k_binv_up(const uint32_t* __restrict__ x, uint32_t* __restrict__ prefix,
+                                                    uint32_t* __restrict__ totals, uint8_t* __restrict__ zero_flags,
+                                                    size_t n, const FpParams<N> P) {
+    const size_t tile = (size_t)blockIdx.x * (kBlock * C);
+    const size_t chain = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    size_t e = tile + threadIdx.x;
+    if (e >= n) return;  // chain empty (only in the last tile)
+    uint32_t run[N], v[N], t[N];
+    set_limbs<N>(run, P.one);
+#pragma unroll 1
+    for (int k = 0; k < C && e < n; k++, e += kBlock) {
+        load_elem<N>(v, x, e);
+        store_elem<N>(prefix, e, run);
+        bool z = is_zero<N>(v);
+        if constexpr (LEVEL0) {
+            if (zero_flags) zero_flags[e] = z ? 1 : 0;
+        }
+        // Level 0 takes a zero as one (it is flagged, its slot gets 0).  Above level 0 a
+        // zero total (composite modulus only) must poison its group: keep multiplying so
+        // the zero reaches the top, where the GCD inverse rejects it.
+        if (!z || !LEVEL0) {
+            mont_mul<N>(t, run, v, P);
+#pragma unroll
+            for (int l = 0; l < N; l++) run[l] = t[l];
+        }
+    }
+    store_elem<N>(totals, chain, run);
+}
+
+// inv_totals[chain] holds the inverse of the chain total; poisoned[] (may be null
+// below level 0 bookkeeping) is handled by the fallback kernel, not here.
+template <int N, int C, bool LEVEL0>
+__global__ __launch_bounds__(kBlock) void k_binv_down(const uint32_t* __restrict__ x, uint32_t* __restrict__ out,
+                                                      const uint32_t* __restrict__ inv_totals, size_t n,
+                                                      const FpParams<N> P) {
+    const size_t tile = (size_t)blockIdx.x * (kBlock * C);
+    const size_t chain = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    const size_t first = tile + threadIdx.x;
+    if (first >= n) return;
+    // number of elements in this chain
+    size_t cnt = (n - first + kBlock - 1) / kBlock;
+    if (cnt > (size_t)C) cnt = C;
+    uint32_t run[N], v[N], pre[N], t[N];
+    load_elem<N>(run, inv_totals, chain);
+#pragma unroll 1
+    for (size_t k = cnt; k-- > 0;) {
+        size_t e = first + k * kBlock;
+        load_elem<N>(v, x, e);
+        load_elem<N>(pre, out, e);  // exclusive prefix written by k_binv_up
+        bool z = LEVEL0 && is_zero<N>(v);
+        if (z) {
+#pragma unroll
+            for (int l = 0; l < N; l++) t[l] = 0;
+            store_elem<N>(out, e, t);
+        } else {
+            // Above level 0 a zero total only occurs in a poisoned group (composite
+            // modulus); whatever is written below it is recomputed by k_binv_fallback.
+            mont_mul<N>(t, run, pre, P);
+            store_elem<N>(out, e, t);
+            mont_mul<N>(t, run, v, P);
+#pragma unroll
+            for (int l = 0; l < N; l++) run[l] = t[l];
+        }
+    }
+}
+
+// Top level: invert each remaining total with the exact GCD inverse.  A total that
+// is not invertible (composite modulus only) marks its group as poisoned.
+template <int N>
+__global__ __launch_bounds__(kBlock) void k_binv_top(uint32_t* __restrict__ totals, uint8_t* __restrict__ poisoned,
+                                                     size_t n, const FpParams<N> P) {
+    size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    uint32_t v[N], r[N];
+    load_elem<N>(v, totals, i);
+    bool ok = mont_inv_gcd<N>(r, v, P);
+    if (!ok) {
+#pragma unroll
+        for (int l = 0; l < N; l++) r[l] = 0;
+    }
+    poisoned[i] = ok ? 0 : 1;
+    store_elem<N>(totals, i, r);
+}
+
+// Fallback for composite moduli: every level-0 element whose top-level group is
+// poisoned is inverted on its own (exactly the reference's per-element inv).
+// top_of(e) applies the chain map `levels` times.
+template <int N, int C>
+__global__ __launch_bounds__(kBlock) void k_binv_fallback(const uint32_t* __restrict__ x, uint32_t* __restrict__ out,
+                                                          uint8_t* __restrict__ zero_flags,
+                                                          const uint8_t* __restrict__ poisoned, size_t n, int levels,
+                                                          const FpParams<N> P) {
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t e = (size_t)blockIdx.x * kBlock + threadIdx.x; e < n; e += stride) {
+        size_t idx = e;
+        for (int l = 0; l < levels; l++) idx = (idx / (kBlock * C)) * kBlock + (idx % kBlock);
+        if (!poisoned[idx]) continue;
+        uint32_t v[N], r[N];
+        load_elem<N>(v, x, e);
+        bool ok = mont_inv_gcd<N>(r, v, P);
+        if (!ok) {
+#pragma unroll
+            for (int l = 0; l < N; l++) r[l] = 0;
+        }
+        if (zero_flags) zero_flags[e] = ok ? 0 : 1;
+        store_elem<N>(out, e, r);
+    }
+}
+
+// ---- block-level modular sum (used by mat-vec) -----------------------------------
+template <int N>
+__device__ __forceinline__ void wave_reduce_add(uint32_t (&acc)[N], const FpParams<N>& P) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        uint32_t o[N], r[N];
+#pragma unroll
+        for (int l = 0; l < N; l++) o[l] = __shfl_down(acc[l], off, 64);
+        mod_add<N>(r, acc, o, P);
+#pragma unroll
+        for (int l = 0; l < N; l++) acc[l] = r[l];
+    }
+}
+
+// ---- dense mat-vec: y[i] = sum_j A[i][j] * x[j] -----------------------------------
+// One workgroup per row; lane t takes columns t, t+256, ... (coalesced 2 KiB per
+// wave-load of A; x is re-read by every row and stays L2-resident), keeps a
+// canonical partial sum, then the block tree-reduces 256 partials with mod_add.
+template <int N>
+__global__ __launch_bounds__(kBlock) void k_matvec(const uint32_t* __restrict__ A, const uint32_t* __restrict__ x,
+                                                   uint32_t* __restrict__ y, size_t rows, size_t cols,
+                                                   const FpParams<N> P) {
+    __shared__ uint32_t part[kBlock / 64][N];
+    for (size_t row = blockIdx.x; row < rows; row += gridDim.x) {
+        const uint32_t* Arow = A + row * cols * N;
+        uint32_t acc[N];
+#pragma unroll
+        for (int l = 0; l < N; l++) acc[l] = 0;
+        for (size_t j = threadIdx.x; j < cols; j += kBlock) {
+            uint32_t a[N], b[N], pr[N], s[N];
+            load_elem<N>(a, Arow, j);
+            load_elem<N>(b, x, j);
+            mont_mul<N>(pr, a, b, P);
+            mod_add<N>(s, acc, pr, P);
+#pragma unroll
+            for (int l = 0; l < N; l++) acc[l] = s[l];
+        }
+        wave_reduce_add<N>(acc, P);
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        if (lane == 0) {
+#pragma unroll
+            for (int l = 0; l < N; l++) part[wave][l] = acc[l];
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t tot[N], o[N], r[N];
+#pragma unroll
+            for (int l = 0; l < N; l++) tot[l] = part[0][l];
+            for (int w = 1; w < kBlock / 64; w++) {
+#pragma unroll
+                for (int l = 0; l < N; l++) o[l] = part[w][l];
+                mod_add<N>(r, tot, o, P);
+#pragma unroll
+                for (int l = 0; l < N; l++) tot[l] = r[l];
+            }
+            store_elem<N>(y, row, tot);
+        }
+        __syncthreads();
+    }
+}
+
+// ---- dense mat-mul: C = A (m x k) * B (k x n), LDS-tiled -------------------------
+// 16 x 16 outputs per workgroup, one per lane; K walked in 16-wide tiles staged in
+// LDS.  First correct version; the register-tiled lazy-reduction variant for the
+// single-limb case replaces it in a later round.
+constexpr int kMMTile = 16;
+template <int N>
+__global__ __launch_bounds__(kMMTile* kMMTile) void k_matmul(const uint32_t* __restrict__ A,
+                                                             const uint32_t* __restrict__ B,
+                                                             uint32_t* __restrict__ Cm, size_t m, size_t k, size_t n,
+                                                             const FpParams<N> P) {
+    __shared__ uint32_t sA[kMMTile][kMMTile][N];
+    __shared__ uint32_t sB[kMMTile][kMMTile][N];
+    const int tx = threadIdx.x % kMMTile, ty = threadIdx.x / kMMTile;
+    const size_t row = (size_t)blockIdx.y * kMMTile + ty;
+    const size_t col = (size_t)blockIdx.x * kMMTile + tx;
+    uint32_t acc[N];
+#pragma unroll
+    for (int l = 0; l < N; l++) acc[l] = 0;
+    for (size_t k0 = 0; k0 < k; k0 += kMMTile) {
+        uint32_t v[N];
+        if (row < m && k0 + tx < k) load_elem<N>(v, A, row * k + k0 + tx);
+        else {
+#pragma unroll
+            for (int l = 0; l < N; l++) v[l] = 0;
+        }
+#pragma unroll
+        for (int l = 0; l < N; l++) sA[ty][tx][l] = v[l];
+        if (k0 + ty < k && col < n) load_elem<N>(v, B, (k0 + ty) * n + col);
+        else {
+#pragma unroll
+            for (int l = 0; l < N; l++) v[l] = 0;
+        }
+#pragma unroll
+        for (int l = 0; l < N; l++) sB[ty][tx][l] = v[l];
+        __syncthreads();
+#pragma unroll 1
+        for (int kk = 0; kk < kMMTile; kk++) {
+            uint32_t a[N], b[N], pr[N], s[N];
+#pragma unroll
+            for (int l = 0; l < N; l++) { a[l] = sA[ty][kk][l]; b[l] = sB[kk][tx][l]; }
+            mont_mul<N>(pr, a, b, P);
+            mod_add<N>(s, acc, pr, P);
+#pragma unroll
+            for (int l = 0; l < N; l++) acc[l] = s[l];
+        }
+        __syncthreads();
+    }
+    if (row < m && col < n) store_elem<N>(Cm, row * n + col, acc);
+}
+
+}  // namespace fpgpu

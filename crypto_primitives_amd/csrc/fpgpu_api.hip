@@ -1,0 +1,539 @@
+// fpgpu_api.hip -- the C ABI of include/fpgpu.h: context, host-side Montgomery
+// parameters, argument checks and kernel dispatch.  There is no CPU fallback:
+// every batch entry point launches a gfx950 kernel or returns an error.
+#include "../../include/fpgpu.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "fp_kernels.cuh"
+
+using namespace fpgpu;
+
+namespace {
+
+thread_local std::string g_last_error = "";
+
+int fail(int code, const std::string& msg) {
+    g_last_error = msg;
+    return code;
+}
+int hip_fail(hipError_t e, const char* what) {
+    return fail(FPGPU_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+#define HIP_TRY(expr)                                  \
+    do {                                               \
+        hipError_t _e = (expr);                        \
+        if (_e != hipSuccess) return hip_fail(_e, #expr); \
+    } while (0)
+
+// ---- host-side big integers (product code: parameter set-up only) ----------------
+using u128 = unsigned __int128;
+
+int cmp_words(const uint64_t* a, const uint64_t* b, int n) {
+    for (int i = n - 1; i >= 0; i--)
+        if (a[i] != b[i]) return a[i] < b[i] ? -1 : 1;
+    return 0;
+}
+void sub_words(uint64_t* r, const uint64_t* a, const uint64_t* b, int n) {
+    uint64_t bo = 0;
+    for (int i = 0; i < n; i++) {
+        u128 t = (u128)a[i] - b[i] - bo;
+        r[i] = (uint64_t)t;
+        bo = (uint64_t)(t >> 64) & 1;
+    }
+}
+// a = 2a mod p for a < p
+void double_mod(uint64_t* a, const uint64_t* p, int n) {
+    uint64_t top = a[n - 1] >> 63;
+    for (int i = n - 1; i > 0; i--) a[i] = (a[i] << 1) | (a[i - 1] >> 63);
+    a[0] <<= 1;
+    if (top || cmp_words(a, p, n) >= 0) sub_words(a, a, p, n);
+}
+// -m^-1 mod 2^64 by Newton iteration (the reference does the same six steps,
+// src/helpers/crypto_bigint.rs:56-67)
+uint64_t neg_inv64(uint64_t m0) {
+    uint64_t inv = 1;
+    for (int i = 0; i < 6; i++) inv *= 2 - m0 * inv;
+    return 0 - inv;
+}
+
+}  // namespace
+
+struct fpgpu_ctx {
+    uint32_t n64;
+    uint64_t modulus[FPGPU_MAX_N64];
+    uint64_t one[FPGPU_MAX_N64];
+    uint64_t r2[FPGPU_MAX_N64];
+    uint64_t mod_neg_inv;
+    uint64_t top_mask;  // significant bits of the top word of the modulus
+};
+
+namespace {
+
+template <int N>
+FpParams<N> make_params(const fpgpu_ctx* c) {
+    FpParams<N> P;
+    for (int i = 0; i < N / 2; i++) {
+        P.m[2 * i] = (uint32_t)c->modulus[i];
+        P.m[2 * i + 1] = (uint32_t)(c->modulus[i] >> 32);
+        P.r2[2 * i] = (uint32_t)c->r2[i];
+        P.r2[2 * i + 1] = (uint32_t)(c->r2[i] >> 32);
+        P.one[2 * i] = (uint32_t)c->one[i];
+        P.one[2 * i + 1] = (uint32_t)(c->one[i] >> 32);
+    }
+    P.n0inv = (uint32_t)c->mod_neg_inv;
+    P.top_mask = (uint32_t)c->top_mask;
+    P.top_mask_hi = (uint32_t)(c->top_mask >> 32);
+    return P;
+}
+
+int grid_for(size_t n) {
+    // HBM-streaming kernels: enough workgroups to fill 256 CUs x 8, grid-stride the
+    // rest (tools/ubench_hbm.hip: 8192-16384 workgroups is the sweet spot on MI355X).
+    size_t blocks = (n + kBlock - 1) / kBlock;
+    return (int)std::min<size_t>(std::max<size_t>(blocks, 1), 16384);
+}
+
+int check_common(const fpgpu_ctx* ctx, size_t n) {
+    if (!ctx) return fail(FPGPU_ERR_SHAPE, "null context");
+    if (n > ((size_t)1 << 40)) return fail(FPGPU_ERR_SHAPE, "element count too large");
+    return FPGPU_OK;
+}
+int check_ptr(const fpgpu_ctx* ctx, const void* p, const char* name) {
+    if (!p) return fail(FPGPU_ERR_SHAPE, std::string("null pointer: ") + name);
+    uintptr_t align = (ctx->n64 % 2 == 0) ? 16 : 8;
+    if ((uintptr_t)p % align) return fail(FPGPU_ERR_SHAPE, std::string("misaligned device pointer: ") + name);
+    return FPGPU_OK;
+}
+#define CHECK(expr)                 \
+    do {                            \
+        int _rc = (expr);           \
+        if (_rc != FPGPU_OK) return _rc; \
+    } while (0)
+
+// Dispatch on the compiled limb counts.
+#define DISPATCH_N64(n64, ...)                                                      \
+    switch (n64) {                                                                  \
+        case 1: { constexpr int N = 2; __VA_ARGS__; } break;                               \
+        case 2: { constexpr int N = 4; __VA_ARGS__; } break;                               \
+        case 3: { constexpr int N = 6; __VA_ARGS__; } break;                               \
+        case 4: { constexpr int N = 8; __VA_ARGS__; } break;                               \
+        case 5: { constexpr int N = 10; __VA_ARGS__; } break;                              \
+        case 6: { constexpr int N = 12; __VA_ARGS__; } break;                              \
+        case 7: { constexpr int N = 14; __VA_ARGS__; } break;                              \
+        case 8: { constexpr int N = 16; __VA_ARGS__; } break;                              \
+        default: return fail(FPGPU_ERR_UNSUPPORTED, "unsupported limb count");      \
+    }
+
+template <int N, int OP>
+void launch_elementwise(const fpgpu_ctx* ctx, const void* a, const void* b, void* out, size_t n, hipStream_t s) {
+    hipLaunchKernelGGL((k_elementwise<N, OP>), dim3(grid_for(n)), dim3(kBlock), 0, s, (const uint32_t*)a,
+                       (const uint32_t*)b, (uint32_t*)out, n, make_params<N>(ctx));
+}
+
+template <int OP>
+int elementwise_dev(const fpgpu_ctx* ctx, const void* a, const void* b, void* out, size_t n, void* stream) {
+    CHECK(check_common(ctx, n));
+    if (n == 0) return FPGPU_OK;
+    CHECK(check_ptr(ctx, a, "a"));
+    if (OP == OP_MUL || OP == OP_ADD || OP == OP_SUB) CHECK(check_ptr(ctx, b, "b"));
+    CHECK(check_ptr(ctx, out, "out"));
+    hipStream_t s = (hipStream_t)stream;
+    DISPATCH_N64(ctx->n64, launch_elementwise<N, OP>(ctx, a, b, out, n, s));
+    HIP_TRY(hipGetLastError());
+    return FPGPU_OK;
+}
+
+// ---- batch inversion plan -----------------------------------------------------------
+constexpr int kInvC = 8;            // chain length per lane
+constexpr size_t kInvTop = 1024;    // stop recursing when this few totals remain
+constexpr int kInvMaxLevels = 16;
+
+struct InvPlan {
+    int levels = 0;                         // number of up-sweeps
+    size_t count[kInvMaxLevels + 1] = {0};  // count[0] = n, count[l+1] = chains at level l
+    size_t x_off[kInvMaxLevels + 1] = {0};  // byte offset of X_l (l >= 1) in the workspace
+    size_t o_off[kInvMaxLevels + 1] = {0};  // byte offset of O_l (1 <= l < levels)
+    size_t poison_off = 0;
+    size_t bytes = 0;
+};
+
+InvPlan make_inv_plan(uint32_t n64, size_t n) {
+    InvPlan p;
+    const size_t tile = (size_t)kBlock * kInvC;
+    const size_t esz = (size_t)n64 * 8;
+    p.count[0] = n;
+    // at least one level, so the top always works on chain totals
+    while (p.levels < kInvMaxLevels && (p.levels == 0 || p.count[p.levels] > kInvTop)) {
+        size_t c = p.count[p.levels];
+        p.count[p.levels + 1] = (c / tile) * kBlock + std::min<size_t>(c % tile, kBlock);
+        p.levels++;
+    }
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+    for (int l = 1; l <= p.levels; l++) p.x_off[l] = take(p.count[l] * esz);
+    for (int l = 1; l < p.levels; l++) p.o_off[l] = take(p.count[l] * esz);
+    p.poison_off = take(p.count[p.levels]);
+    p.bytes = off;
+    return p;
+}
+
+template <int N>
+int batch_inv_launch(const fpgpu_ctx* ctx, const void* x, void* out, uint8_t* flags, size_t n, char* ws,
+                     hipStream_t s) {
+    const InvPlan p = make_inv_plan(ctx->n64, n);
+    const FpParams<N> P = make_params<N>(ctx);
+    const size_t tile = (size_t)kBlock * kInvC;
+    auto X = [&](int l) -> const uint32_t* { return l == 0 ? (const uint32_t*)x : (const uint32_t*)(ws + p.x_off[l]); };
+    auto O = [&](int l) -> uint32_t* { return l == 0 ? (uint32_t*)out : (uint32_t*)(ws + p.o_off[l]); };
+    uint8_t* poisoned = (uint8_t*)(ws + p.poison_off);
+    // up-sweeps
+    for (int l = 0; l < p.levels; l++) {
+        int blocks = (int)((p.count[l] + tile - 1) / tile);
+        uint32_t* totals = (uint32_t*)(ws + p.x_off[l + 1]);
+        if (l == 0)
+            hipLaunchKernelGGL((k_binv_up<N, kInvC, true>), dim3(blocks), dim3(kBlock), 0, s, X(0), O(0), totals,
+                               flags, p.count[0], P);
+        else
+            hipLaunchKernelGGL((k_binv_up<N, kInvC, false>), dim3(blocks), dim3(kBlock), 0, s, X(l), O(l), totals,
+                               (uint8_t*)nullptr, p.count[l], P);
+    }
+    // top: exact inverses of the remaining totals, in place
+    {
+        size_t c = p.count[p.levels];
+        int blocks = (int)((c + kBlock - 1) / kBlock);
+        hipLaunchKernelGGL((k_binv_top<N>), dim3(blocks), dim3(kBlock), 0, s, (uint32_t*)(ws + p.x_off[p.levels]),
+                           poisoned, c, P);
+    }
+    // down-sweeps
+    for (int l = p.levels - 1; l >= 0; l--) {
+        int blocks = (int)((p.count[l] + tile - 1) / tile);
+        const uint32_t* inv_totals =
+            (l + 1 == p.levels) ? (const uint32_t*)(ws + p.x_off[l + 1]) : (const uint32_t*)O(l + 1);
+        if (l == 0)
+            hipLaunchKernelGGL((k_binv_down<N, kInvC, true>), dim3(blocks), dim3(kBlock), 0, s, X(0), O(0),
+                               inv_totals, p.count[0], P);
+        else
+            hipLaunchKernelGGL((k_binv_down<N, kInvC, false>), dim3(blocks), dim3(kBlock), 0, s, X(l), O(l),
+                               inv_totals, p.count[l], P);
+    }
+    // composite-modulus safety net (a no-op unless a top-level total was not invertible)
+    hipLaunchKernelGGL((k_binv_fallback<N, kInvC>), dim3(grid_for(n)), dim3(kBlock), 0, s, (const uint32_t*)x,
+                       (uint32_t*)out, flags, poisoned, n, p.levels, P);
+    return FPGPU_OK;
+}
+
+// ---- host staging helper --------------------------------------------------------------
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int alloc(size_t bytes) {
+        hipError_t e = hipMalloc(&p, std::max<size_t>(bytes, 16));
+        if (e != hipSuccess) { p = nullptr; return hip_fail(e, "hipMalloc"); }
+        return FPGPU_OK;
+    }
+};
+
+int require_device() {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        return fail(FPGPU_ERR_NO_DEVICE, "no HIP device visible: libfpgpu has no CPU fallback");
+    }
+    return FPGPU_OK;
+}
+
+template <typename F>
+int host_binary(const fpgpu_ctx* ctx, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, bool has_b,
+                F&& dev_call) {
+    CHECK(check_common(ctx, n));
+    if (n == 0) return FPGPU_OK;
+    if (!a || !out || (has_b && !b)) return fail(FPGPU_ERR_SHAPE, "null host pointer");
+    CHECK(require_device());
+    size_t bytes = n * ctx->n64 * 8;
+    DevBuf da, db, dout;
+    CHECK(da.alloc(bytes));
+    if (has_b) CHECK(db.alloc(bytes));
+    CHECK(dout.alloc(bytes));
+    HIP_TRY(hipMemcpy(da.p, a, bytes, hipMemcpyHostToDevice));
+    if (has_b) HIP_TRY(hipMemcpy(db.p, b, bytes, hipMemcpyHostToDevice));
+    CHECK(dev_call(da.p, db.p, dout.p));
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    HIP_TRY(hipMemcpy(out, dout.p, bytes, hipMemcpyDeviceToHost));
+    return FPGPU_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fpgpu_ctx_create(const uint64_t* modulus_le, uint32_t n64, fpgpu_ctx** out) {
+    if (!modulus_le || !out) return fail(FPGPU_ERR_SHAPE, "null pointer");
+    *out = nullptr;
+    if (n64 == 0 || n64 > FPGPU_MAX_N64) return fail(FPGPU_ERR_UNSUPPORTED, "n64 must be in 1..8");
+    if ((modulus_le[0] & 1) == 0) return fail(FPGPU_ERR_INVALID_MODULUS, "modulus must be odd");
+    fpgpu_ctx* c = new (std::nothrow) fpgpu_ctx();
+    if (!c) return fail(FPGPU_ERR_HIP, "out of host memory");
+    c->n64 = n64;
+    std::memset(c->modulus, 0, sizeof c->modulus);
+    std::memcpy(c->modulus, modulus_le, n64 * 8);
+    c->mod_neg_inv = neg_inv64(modulus_le[0]);
+    // R mod p and R^2 mod p by 64*n64 modular doublings each, starting from 1 mod p.
+    uint64_t t[FPGPU_MAX_N64] = {0};
+    t[0] = 1;
+    if (cmp_words(t, c->modulus, n64) >= 0) sub_words(t, t, c->modulus, n64);  // p == 1
+    for (uint32_t i = 0; i < 64 * n64; i++) double_mod(t, c->modulus, n64);
+    std::memcpy(c->one, t, sizeof t);
+    for (uint32_t i = 0; i < 64 * n64; i++) double_mod(t, c->modulus, n64);
+    std::memcpy(c->r2, t, sizeof t);
+    // bit mask of the modulus' top word (for the synthetic generator)
+    uint64_t top = c->modulus[n64 - 1];
+    uint64_t mask = ~(uint64_t)0;
+    if (top != 0) {
+        int lz = __builtin_clzll(top);
+        mask = lz ? (((uint64_t)1 << (64 - lz)) - 1) : ~(uint64_t)0;
+    }
+    c->top_mask = mask;
+    *out = c;
+    return FPGPU_OK;
+}
+
+void fpgpu_ctx_destroy(fpgpu_ctx* ctx) { delete ctx; }
+
+uint32_t fpgpu_ctx_n64(const fpgpu_ctx* ctx) { return ctx ? ctx->n64 : 0; }
+
+int fpgpu_ctx_params(const fpgpu_ctx* ctx, uint64_t* modulus_le, uint64_t* one_le, uint64_t* r2_le,
+                     uint64_t* mod_neg_inv) {
+    if (!ctx) return fail(FPGPU_ERR_SHAPE, "null context");
+    if (modulus_le) std::memcpy(modulus_le, ctx->modulus, ctx->n64 * 8);
+    if (one_le) std::memcpy(one_le, ctx->one, ctx->n64 * 8);
+    if (r2_le) std::memcpy(r2_le, ctx->r2, ctx->n64 * 8);
+    if (mod_neg_inv) *mod_neg_inv = ctx->mod_neg_inv;
+    return FPGPU_OK;
+}
+
+int fpgpu_mul_dev(const fpgpu_ctx* ctx, const void* a, const void* b, void* out, size_t n, void* stream) {
+    return elementwise_dev<OP_MUL>(ctx, a, b, out, n, stream);
+}
+int fpgpu_sqr_dev(const fpgpu_ctx* ctx, const void* a, void* out, size_t n, void* stream) {
+    return elementwise_dev<OP_SQR>(ctx, a, nullptr, out, n, stream);
+}
+int fpgpu_add_dev(const fpgpu_ctx* ctx, const void* a, const void* b, void* out, size_t n, void* stream) {
+    return elementwise_dev<OP_ADD>(ctx, a, b, out, n, stream);
+}
+int fpgpu_sub_dev(const fpgpu_ctx* ctx, const void* a, const void* b, void* out, size_t n, void* stream) {
+    return elementwise_dev<OP_SUB>(ctx, a, b, out, n, stream);
+}
+int fpgpu_neg_dev(const fpgpu_ctx* ctx, const void* a, void* out, size_t n, void* stream) {
+    return elementwise_dev<OP_NEG>(ctx, a, nullptr, out, n, stream);
+}
+int fpgpu_to_mont_dev(const fpgpu_ctx* ctx, const void* a, void* out, size_t n, void* stream) {
+    return elementwise_dev<OP_TO_MONT>(ctx, a, nullptr, out, n, stream);
+}
+int fpgpu_from_mont_dev(const fpgpu_ctx* ctx, const void* a, void* out, size_t n, void* stream) {
+    return elementwise_dev<OP_FROM_MONT>(ctx, a, nullptr, out, n, stream);
+}
+
+int fpgpu_mul_chain_dev(const fpgpu_ctx* ctx, const void* a, const void* b, void* out, size_t n, uint32_t iters,
+                        void* stream) {
+    CHECK(check_common(ctx, n));
+    if (n == 0) return FPGPU_OK;
+    CHECK(check_ptr(ctx, a, "a"));
+    CHECK(check_ptr(ctx, b, "b"));
+    CHECK(check_ptr(ctx, out, "out"));
+    hipStream_t s = (hipStream_t)stream;
+    DISPATCH_N64(ctx->n64, hipLaunchKernelGGL((k_mul_chain<N>), dim3(grid_for(n)), dim3(kBlock), 0, s,
+                                               (const uint32_t*)a, (const uint32_t*)b, (uint32_t*)out, n, iters,
+                                               make_params<N>(ctx)));
+    HIP_TRY(hipGetLastError());
+    return FPGPU_OK;
+}
+
+size_t fpgpu_batch_inv_workspace_bytes(const fpgpu_ctx* ctx, size_t n) {
+    if (!ctx || n == 0) return 0;
+    return make_inv_plan(ctx->n64, n).bytes;
+}
+
+int fpgpu_batch_inv_dev(const fpgpu_ctx* ctx, const void* x, void* out, uint8_t* zero_flags, size_t n,
+                        void* workspace, size_t workspace_bytes, void* stream) {
+    CHECK(check_common(ctx, n));
+    if (n == 0) return FPGPU_OK;
+    CHECK(check_ptr(ctx, x, "x"));
+    CHECK(check_ptr(ctx, out, "out"));
+    if (x == out) return fail(FPGPU_ERR_SHAPE, "batch_inv: out must not alias x");
+    if (!workspace || (uintptr_t)workspace % 16) return fail(FPGPU_ERR_SHAPE, "batch_inv: workspace null or misaligned");
+    if (workspace_bytes < fpgpu_batch_inv_workspace_bytes(ctx, n))
+        return fail(FPGPU_ERR_SHAPE, "batch_inv: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    DISPATCH_N64(ctx->n64, batch_inv_launch<N>(ctx, x, out, zero_flags, n, (char*)workspace, s));
+    HIP_TRY(hipGetLastError());
+    return FPGPU_OK;
+}
+
+int fpgpu_matvec_dev(const fpgpu_ctx* ctx, const void* A, size_t rows, size_t cols, const void* x, void* y,
+                     void* stream) {
+    if (!ctx) return fail(FPGPU_ERR_SHAPE, "null context");
+    if (rows == 0) return FPGPU_OK;
+    if (cols != 0 && rows > ((size_t)1 << 40) / cols) return fail(FPGPU_ERR_SHAPE, "matrix too large");
+    CHECK(check_ptr(ctx, y, "y"));
+    if (cols != 0) {
+        CHECK(check_ptr(ctx, A, "A"));
+        CHECK(check_ptr(ctx, x, "x"));
+    }
+    hipStream_t s = (hipStream_t)stream;
+    int grid = (int)std::min<size_t>(rows, 65536);
+    DISPATCH_N64(ctx->n64, hipLaunchKernelGGL((k_matvec<N>), dim3(grid), dim3(kBlock), 0, s, (const uint32_t*)A,
+                                               (const uint32_t*)x, (uint32_t*)y, rows, cols, make_params<N>(ctx)));
+    HIP_TRY(hipGetLastError());
+    return FPGPU_OK;
+}
+
+int fpgpu_matmul_dev(const fpgpu_ctx* ctx, const void* A, const void* B, void* C, size_t m, size_t k, size_t n,
+                     void* stream) {
+    if (!ctx) return fail(FPGPU_ERR_SHAPE, "null context");
+    if (m == 0 || n == 0) return FPGPU_OK;
+    CHECK(check_ptr(ctx, C, "C"));
+    if (k != 0) {
+        CHECK(check_ptr(ctx, A, "A"));
+        CHECK(check_ptr(ctx, B, "B"));
+    }
+    size_t gx = (n + kMMTile - 1) / kMMTile, gy = (m + kMMTile - 1) / kMMTile;
+    if (gy > 65535 || gx > ((size_t)1 << 31) - 1) return fail(FPGPU_ERR_SHAPE, "matrix too large");
+    hipStream_t s = (hipStream_t)stream;
+    DISPATCH_N64(ctx->n64, hipLaunchKernelGGL((k_matmul<N>), dim3((unsigned)gx, (unsigned)gy), dim3(kMMTile * kMMTile),
+                                               0, s, (const uint32_t*)A, (const uint32_t*)B, (uint32_t*)C, m, k, n,
+                                               make_params<N>(ctx)));
+    HIP_TRY(hipGetLastError());
+    return FPGPU_OK;
+}
+
+int fpgpu_fill_random_dev(const fpgpu_ctx* ctx, void* out, size_t n, uint64_t seed, void* stream) {
+    CHECK(check_common(ctx, n));
+    if (n == 0) return FPGPU_OK;
+    CHECK(check_ptr(ctx, out, "out"));
+    hipStream_t s = (hipStream_t)stream;
+    DISPATCH_N64(ctx->n64, hipLaunchKernelGGL((k_fill_random<N>), dim3(grid_for(n)), dim3(kBlock), 0, s,
+                                               (uint32_t*)out, n, seed, make_params<N>(ctx)));
+    HIP_TRY(hipGetLastError());
+    return FPGPU_OK;
+}
+
+// ---- host-buffer calls -----------------------------------------------------------------
+int fpgpu_mul(const fpgpu_ctx* ctx, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
+    return host_binary(ctx, a, b, out, n, true,
+                       [&](void* da, void* db, void* dout) { return fpgpu_mul_dev(ctx, da, db, dout, n, nullptr); });
+}
+int fpgpu_sqr(const fpgpu_ctx* ctx, const uint64_t* a, uint64_t* out, size_t n) {
+    return host_binary(ctx, a, nullptr, out, n, false,
+                       [&](void* da, void*, void* dout) { return fpgpu_sqr_dev(ctx, da, dout, n, nullptr); });
+}
+int fpgpu_add(const fpgpu_ctx* ctx, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
+    return host_binary(ctx, a, b, out, n, true,
+                       [&](void* da, void* db, void* dout) { return fpgpu_add_dev(ctx, da, db, dout, n, nullptr); });
+}
+int fpgpu_sub(const fpgpu_ctx* ctx, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
+    return host_binary(ctx, a, b, out, n, true,
+                       [&](void* da, void* db, void* dout) { return fpgpu_sub_dev(ctx, da, db, dout, n, nullptr); });
+}
+int fpgpu_neg(const fpgpu_ctx* ctx, const uint64_t* a, uint64_t* out, size_t n) {
+    return host_binary(ctx, a, nullptr, out, n, false,
+                       [&](void* da, void*, void* dout) { return fpgpu_neg_dev(ctx, da, dout, n, nullptr); });
+}
+int fpgpu_to_mont(const fpgpu_ctx* ctx, const uint64_t* a, uint64_t* out, size_t n) {
+    return host_binary(ctx, a, nullptr, out, n, false,
+                       [&](void* da, void*, void* dout) { return fpgpu_to_mont_dev(ctx, da, dout, n, nullptr); });
+}
+int fpgpu_from_mont(const fpgpu_ctx* ctx, const uint64_t* a, uint64_t* out, size_t n) {
+    return host_binary(ctx, a, nullptr, out, n, false,
+                       [&](void* da, void*, void* dout) { return fpgpu_from_mont_dev(ctx, da, dout, n, nullptr); });
+}
+int fpgpu_mul_chain(const fpgpu_ctx* ctx, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n,
+                    uint32_t iters) {
+    return host_binary(ctx, a, b, out, n, true, [&](void* da, void* db, void* dout) {
+        return fpgpu_mul_chain_dev(ctx, da, db, dout, n, iters, nullptr);
+    });
+}
+
+int fpgpu_batch_inv(const fpgpu_ctx* ctx, const uint64_t* x, uint64_t* out, uint8_t* zero_flags, size_t n) {
+    CHECK(check_common(ctx, n));
+    if (n == 0) return FPGPU_OK;
+    if (!x || !out) return fail(FPGPU_ERR_SHAPE, "null host pointer");
+    CHECK(require_device());
+    size_t bytes = n * ctx->n64 * 8;
+    size_t wsb = fpgpu_batch_inv_workspace_bytes(ctx, n);
+    DevBuf dx, dout, dflags, ws;
+    CHECK(dx.alloc(bytes));
+    CHECK(dout.alloc(bytes));
+    CHECK(dflags.alloc(n));
+    CHECK(ws.alloc(wsb));
+    HIP_TRY(hipMemcpy(dx.p, x, bytes, hipMemcpyHostToDevice));
+    CHECK(fpgpu_batch_inv_dev(ctx, dx.p, dout.p, (uint8_t*)dflags.p, n, ws.p, wsb, nullptr));
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    HIP_TRY(hipMemcpy(out, dout.p, bytes, hipMemcpyDeviceToHost));
+    if (zero_flags) HIP_TRY(hipMemcpy(zero_flags, dflags.p, n, hipMemcpyDeviceToHost));
+    return FPGPU_OK;
+}
+
+int fpgpu_matvec(const fpgpu_ctx* ctx, const uint64_t* A, size_t rows, size_t cols, const uint64_t* x, uint64_t* y) {
+    if (!ctx) return fail(FPGPU_ERR_SHAPE, "null context");
+    if (rows == 0) return FPGPU_OK;
+    if (!y || (cols && (!A || !x))) return fail(FPGPU_ERR_SHAPE, "null host pointer");
+    CHECK(require_device());
+    size_t esz = ctx->n64 * 8;
+    DevBuf dA, dx, dy;
+    CHECK(dA.alloc(rows * cols * esz));
+    CHECK(dx.alloc(cols * esz));
+    CHECK(dy.alloc(rows * esz));
+    if (cols) {
+        HIP_TRY(hipMemcpy(dA.p, A, rows * cols * esz, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(dx.p, x, cols * esz, hipMemcpyHostToDevice));
+    }
+    CHECK(fpgpu_matvec_dev(ctx, dA.p, rows, cols, dx.p, dy.p, nullptr));
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    HIP_TRY(hipMemcpy(y, dy.p, rows * esz, hipMemcpyDeviceToHost));
+    return FPGPU_OK;
+}
+
+int fpgpu_matmul(const fpgpu_ctx* ctx, const uint64_t* A, const uint64_t* B, uint64_t* C, size_t m, size_t k,
+                 size_t n) {
+    if (!ctx) return fail(FPGPU_ERR_SHAPE, "null context");
+    if (m == 0 || n == 0) return FPGPU_OK;
+    if (!C || (k && (!A || !B))) return fail(FPGPU_ERR_SHAPE, "null host pointer");
+    CHECK(require_device());
+    size_t esz = ctx->n64 * 8;
+    DevBuf dA, dB, dC;
+    CHECK(dA.alloc(m * k * esz));
+    CHECK(dB.alloc(k * n * esz));
+    CHECK(dC.alloc(m * n * esz));
+    if (k) {
+        HIP_TRY(hipMemcpy(dA.p, A, m * k * esz, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(dB.p, B, k * n * esz, hipMemcpyHostToDevice));
+    }
+    CHECK(fpgpu_matmul_dev(ctx, dA.p, dB.p, dC.p, m, k, n, nullptr));
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    HIP_TRY(hipMemcpy(C, dC.p, m * n * esz, hipMemcpyDeviceToHost));
+    return FPGPU_OK;
+}
+
+const char* fpgpu_last_error_string(void) { return g_last_error.c_str(); }
+
+int fpgpu_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+const char* fpgpu_version(void) { return "fpgpu 0.1.0 (gfx950)"; }
+
+}  // extern "C"

@@ -1,0 +1,206 @@
+"""Python view of the batched field backend: a thin object layer over the C ABI.
+
+Mirrors the reference's config-style interface for the hot path
+(`MontyField::{add, sub, mul, neg, inv, project, lift}`,
+src/field/crypto_bigint_monty.rs:134-250,319-385) in batch form: every method
+takes and returns arrays of Montgomery representatives laid out exactly as the
+reference's `Vec<MontyFieldElement<LIMBS>>` (count x n64 little-endian u64 words).
+
+Host arrays are numpy uint64 (count, n64); device arrays are torch int64 CUDA
+tensors of the same shape (torch has no uint64 arithmetic; the bits are what
+matter).  Nothing here computes on the CPU.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from ._lib import check
+
+
+class InvalidModulus(ValueError):
+    """FieldError::InvalidModulus (src/field.rs:345-349)."""
+
+
+def _np(a, n64):
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    return a.reshape(-1, n64)
+
+
+def _ptr(a):
+    return ctypes.c_void_p(a.ctypes.data)
+
+
+class MontyField:
+    """Runtime-modulus prime field, batched (BaseFieldConfig::new + batch ops)."""
+
+    def __init__(self, modulus: int, n64: int):
+        lib = _lib.load()
+        self.n64 = n64
+        self.modulus_int = modulus
+        words = np.array([(modulus >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(n64)], dtype=np.uint64)
+        if modulus >> (64 * n64):
+            raise ValueError("modulus does not fit n64 words")
+        h = ctypes.c_void_p()
+        rc = lib.fpgpu_ctx_create(_ptr(words), n64, ctypes.byref(h))
+        if rc == _lib.ERR_INVALID_MODULUS:
+            raise InvalidModulus(lib.fpgpu_last_error_string().decode())
+        check(rc)
+        self._h = h
+        self._lib = lib
+        m = np.zeros(n64, dtype=np.uint64)
+        one = np.zeros(n64, dtype=np.uint64)
+        r2 = np.zeros(n64, dtype=np.uint64)
+        inv = ctypes.c_uint64()
+        check(lib.fpgpu_ctx_params(h, _ptr(m), _ptr(one), _ptr(r2), ctypes.byref(inv)))
+        self.modulus_words, self.one_words, self.r2_words, self.mod_neg_inv = m, one, r2, inv.value
+
+    @classmethod
+    def new(cls, modulus: int, n64: int):
+        return cls(modulus, n64)
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                self._lib.fpgpu_ctx_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    # -- identities ------------------------------------------------------------------
+    def zero(self):
+        return np.zeros(self.n64, dtype=np.uint64)
+
+    def one(self):
+        return self.one_words.copy()
+
+    # -- host-array batch ops (synchronous; H2D + kernel + D2H inside the library) ----
+    def _bin(self, fn, a, b):
+        a, b = _np(a, self.n64), _np(b, self.n64)
+        if a.shape != b.shape:
+            raise ValueError("operand length mismatch")
+        out = np.empty_like(a)
+        check(fn(self._h, _ptr(a), _ptr(b), _ptr(out), a.shape[0]))
+        return out
+
+    def _un(self, fn, a):
+        a = _np(a, self.n64)
+        out = np.empty_like(a)
+        check(fn(self._h, _ptr(a), _ptr(out), a.shape[0]))
+        return out
+
+    def mul(self, a, b): return self._bin(self._lib.fpgpu_mul, a, b)
+    def add(self, a, b): return self._bin(self._lib.fpgpu_add, a, b)
+    def sub(self, a, b): return self._bin(self._lib.fpgpu_sub, a, b)
+    def sqr(self, a): return self._un(self._lib.fpgpu_sqr, a)
+    def neg(self, a): return self._un(self._lib.fpgpu_neg, a)
+    def project(self, a): return self._un(self._lib.fpgpu_to_mont, a)    # integers -> Montgomery form
+    def lift(self, a): return self._un(self._lib.fpgpu_from_mont, a)     # Montgomery form -> integers
+
+    def mul_chain(self, a, b, iters):
+        a, b = _np(a, self.n64), _np(b, self.n64)
+        out = np.empty_like(a)
+        check(self._lib.fpgpu_mul_chain(self._h, _ptr(a), _ptr(b), _ptr(out), a.shape[0], iters))
+        return out
+
+    def inv(self, x):
+        """Batch FieldConfig::inv.  Returns (out, none_flags): none_flags[i] = 1 where the
+        reference returns None (out[i] = 0 there)."""
+        x = _np(x, self.n64)
+        out = np.empty_like(x)
+        flags = np.zeros(x.shape[0], dtype=np.uint8)
+        check(self._lib.fpgpu_batch_inv(self._h, _ptr(x), _ptr(out), _ptr(flags), x.shape[0]))
+        return out, flags
+
+    def div(self, a, b):
+        """Batch FieldConfig::div (src/field.rs:155-157): raises on a zero divisor."""
+        invb, flags = self.inv(b)
+        if flags.any():
+            raise ZeroDivisionError("Division by zero")
+        return self.mul(a, invb)
+
+    def matvec(self, A, rows, cols, x):
+        A, x = _np(A, self.n64), _np(x, self.n64)
+        if A.shape[0] != rows * cols or x.shape[0] != cols:
+            raise ValueError("matrix / vector shape mismatch")
+        y = np.zeros((rows, self.n64), dtype=np.uint64)
+        check(self._lib.fpgpu_matvec(self._h, _ptr(A), rows, cols, _ptr(x), _ptr(y)))
+        return y
+
+    def matmul(self, A, B, m, k, n):
+        A, B = _np(A, self.n64), _np(B, self.n64)
+        if A.shape[0] != m * k or B.shape[0] != k * n:
+            raise ValueError("matrix shape mismatch")
+        C = np.zeros((m * n, self.n64), dtype=np.uint64)
+        check(self._lib.fpgpu_matmul(self._h, _ptr(A), _ptr(B), _ptr(C), m, k, n))
+        return C
+
+    # -- device-tensor batch ops (asynchronous on torch's current stream) --------------
+    @staticmethod
+    def _stream():
+        import torch
+        return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def _chk_t(self, t):
+        if not t.is_cuda or not t.is_contiguous() or t.element_size() != 8 or t.shape[-1] != self.n64:
+            raise ValueError("expected a contiguous CUDA tensor of 8-byte words with last dim n64")
+        return ctypes.c_void_p(t.data_ptr())
+
+    def alloc(self, n, device=None):
+        import torch
+        return torch.empty((n, self.n64), dtype=torch.int64, device=device or "cuda")
+
+    def random_dev(self, n, seed, device=None):
+        t = self.alloc(n, device)
+        check(self._lib.fpgpu_fill_random_dev(self._h, self._chk_t(t), n, seed, self._stream()))
+        return t
+
+    def mul_dev(self, a, b, out):
+        check(self._lib.fpgpu_mul_dev(self._h, self._chk_t(a), self._chk_t(b), self._chk_t(out), a.shape[0], self._stream()))
+        return out
+
+    def add_dev(self, a, b, out):
+        check(self._lib.fpgpu_add_dev(self._h, self._chk_t(a), self._chk_t(b), self._chk_t(out), a.shape[0], self._stream()))
+        return out
+
+    def sub_dev(self, a, b, out):
+        check(self._lib.fpgpu_sub_dev(self._h, self._chk_t(a), self._chk_t(b), self._chk_t(out), a.shape[0], self._stream()))
+        return out
+
+    def sqr_dev(self, a, out):
+        check(self._lib.fpgpu_sqr_dev(self._h, self._chk_t(a), self._chk_t(out), a.shape[0], self._stream()))
+        return out
+
+    def neg_dev(self, a, out):
+        check(self._lib.fpgpu_neg_dev(self._h, self._chk_t(a), self._chk_t(out), a.shape[0], self._stream()))
+        return out
+
+    def to_mont_dev(self, a, out):
+        check(self._lib.fpgpu_to_mont_dev(self._h, self._chk_t(a), self._chk_t(out), a.shape[0], self._stream()))
+        return out
+
+    def from_mont_dev(self, a, out):
+        check(self._lib.fpgpu_from_mont_dev(self._h, self._chk_t(a), self._chk_t(out), a.shape[0], self._stream()))
+        return out
+
+    def mul_chain_dev(self, a, b, out, iters):
+        check(self._lib.fpgpu_mul_chain_dev(self._h, self._chk_t(a), self._chk_t(b), self._chk_t(out), a.shape[0], iters, self._stream()))
+        return out
+
+    def inv_workspace_bytes(self, n):
+        return self._lib.fpgpu_batch_inv_workspace_bytes(self._h, n)
+
+    def inv_dev(self, x, out, flags, workspace):
+        fp = ctypes.c_void_p(flags.data_ptr()) if flags is not None else None
+        check(self._lib.fpgpu_batch_inv_dev(self._h, self._chk_t(x), self._chk_t(out), fp, x.shape[0],
+                                            ctypes.c_void_p(workspace.data_ptr()), workspace.numel() * workspace.element_size(),
+                                            self._stream()))
+        return out
+
+    def matvec_dev(self, A, rows, cols, x, y):
+        check(self._lib.fpgpu_matvec_dev(self._h, self._chk_t(A), rows, cols, self._chk_t(x), self._chk_t(y), self._stream()))
+        return y
+
+    def matmul_dev(self, A, B, C, m, k, n):
+        check(self._lib.fpgpu_matmul_dev(self._h, self._chk_t(A), self._chk_t(B), self._chk_t(C), m, k, n, self._stream()))
+        return C

@@ -1,0 +1,145 @@
+/*
+ * fpgpu.h -- C ABI of libfpgpu: the MI355X (gfx950) backend for crypto-primitives'
+ * prime-field Montgomery hot path.
+ *
+ * The reference (Rust) has no slice-level entry point: its Field / FieldConfig
+ * methods are scalar (src/semiring.rs:138-242, src/ring.rs:45-56,
+ * src/field.rs:146-187).  Each function below is the batched form of one of
+ * those scalar methods and is what a Rust `fpgpu-sys` crate would bind
+ * (INTEGRATION.md shows the extern block and the adapter).  Plain pointers and
+ * sizes only.
+ *
+ * Element layout (both host and device buffers): element i occupies n64
+ * consecutive little-endian uint64_t words at index i*n64 -- exactly
+ * `Uint::as_words()` (src/semiring/crypto_bigint_uint.rs:65-68) laid out as a
+ * `Vec<T>` / `DenseRowMatrix<T>::data` (src/matrix.rs:135-145).  No transposition,
+ * no copy-in format: a `&[MontyFieldElement<LIMBS>]` can be passed as is.
+ * All field elements are Montgomery representatives with R = 2^(64*n64), as in
+ * the reference.  Results are canonical ([0, p)) and bit-identical to the
+ * reference's.
+ *
+ * Device pointers must be 16-byte aligned (8-byte for n64 odd).  Every *_dev
+ * call is asynchronous on `stream` (a hipStream_t, NULL = default stream) of the
+ * current HIP device and allocates nothing.  The host-buffer calls are
+ * synchronous, run on the current device, and stage through device memory they
+ * allocate and free themselves.
+ */
+#ifndef FPGPU_H
+#define FPGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct fpgpu_ctx fpgpu_ctx;
+
+enum {
+    FPGPU_OK = 0,
+    FPGPU_ERR_INVALID_MODULUS = 1, /* even or zero modulus: FieldError::InvalidModulus (src/field.rs:345-349) */
+    FPGPU_ERR_UNSUPPORTED = 2,     /* limb count without a compiled kernel */
+    FPGPU_ERR_SHAPE = 3,           /* null pointer / size / alignment mismatch */
+    FPGPU_ERR_HIP = 4,             /* a HIP runtime call failed; see fpgpu_last_error_string() */
+    FPGPU_ERR_NO_DEVICE = 5        /* no gfx950 device visible: there is no CPU fallback */
+};
+
+#define FPGPU_MAX_N64 8 /* largest compiled element width: 512 bits */
+
+/* ---- field configuration -------------------------------------------------
+ * Replaces BaseFieldConfig::new (src/field.rs:197-209; MontyField impl
+ * src/field/crypto_bigint_monty.rs:346-363, BoxedMontyField impl
+ * src/field/crypto_bigint_boxed_monty.rs:406-412) together with
+ * crypto-bigint's MontyParams::new: computes -m^-1 mod 2^64
+ * (src/helpers/crypto_bigint.rs:56-67), R mod p and R^2 mod p.
+ * `modulus_le` holds n64 little-endian words.  An even or zero modulus returns
+ * FPGPU_ERR_INVALID_MODULUS.  The context is immutable and may be shared
+ * between threads (the reference's configs are Send + Sync, src/lib.rs:62-65). */
+int fpgpu_ctx_create(const uint64_t *modulus_le, uint32_t n64, fpgpu_ctx **out);
+void fpgpu_ctx_destroy(fpgpu_ctx *ctx);
+uint32_t fpgpu_ctx_n64(const fpgpu_ctx *ctx);
+/* modulus(), params.one(), params.r2(), params.mod_neg_inv()
+ * (crypto_bigint_monty.rs:144,169,234,355-357).  Any output pointer may be NULL. */
+int fpgpu_ctx_params(const fpgpu_ctx *ctx, uint64_t *modulus_le, uint64_t *one_le,
+                     uint64_t *r2_le, uint64_t *mod_neg_inv);
+
+/* ---- elementwise batches, device buffers ----------------------------------
+ * out[i] = op(a[i], b[i]) for i in [0, n).  `out` may alias `a` or `b`. */
+
+/* SemiringConfig::mul -> helpers::mul::monty_mul (crypto_bigint_monty.rs:159-161,
+ * src/helpers/crypto_bigint.rs:74-159); ConstMontyField MulAssign
+ * (crypto_bigint_const_monty.rs:337-347); BoxedMontyField::mul
+ * (crypto_bigint_boxed_monty.rs:182-196). */
+int fpgpu_mul_dev(const fpgpu_ctx *ctx, const void *a, const void *b, void *out, size_t n, void *stream);
+/* Square (crypto_bigint_const_monty.rs:736-740): a*a*R^-1 mod p. */
+int fpgpu_sqr_dev(const fpgpu_ctx *ctx, const void *a, void *out, size_t n, void *stream);
+/* SemiringConfig::add -> add_mod (crypto_bigint_monty.rs:147-151, const_monty.rs:317-325). */
+int fpgpu_add_dev(const fpgpu_ctx *ctx, const void *a, const void *b, void *out, size_t n, void *stream);
+/* SemiringConfig::sub -> sub_mod (crypto_bigint_monty.rs:153-157, const_monty.rs:327-335). */
+int fpgpu_sub_dev(const fpgpu_ctx *ctx, const void *a, const void *b, void *out, size_t n, void *stream);
+/* RingConfig::neg -> neg_mod, 0 -> 0 (crypto_bigint_monty.rs:198-202, const_monty.rs:191-202). */
+int fpgpu_neg_dev(const fpgpu_ctx *ctx, const void *a, void *out, size_t n, void *stream);
+/* project(&Uint): integer -> Montgomery form = monty_mul(x, R^2); x may be any n64-word
+ * value, also >= p (crypto_bigint_monty.rs:319-340, const_monty.rs:497-506). */
+int fpgpu_to_mont_dev(const fpgpu_ctx *ctx, const void *a, void *out, size_t n, void *stream);
+/* lift: Montgomery form -> canonical integer = monty_retrieve_inner
+ * (crypto_bigint_monty.rs:369-385, src/helpers/crypto_bigint.rs:13-37). */
+int fpgpu_from_mont_dev(const fpgpu_ctx *ctx, const void *a, void *out, size_t n, void *stream);
+/* "Mul assign" bench shape (benches/field_ops_bench_common.rs:27-39), batched:
+ * acc[i] = a[i]; repeat `iters` times acc[i] = mul(acc[i], b[i]); out[i] = acc[i]. */
+int fpgpu_mul_chain_dev(const fpgpu_ctx *ctx, const void *a, const void *b, void *out, size_t n,
+                        uint32_t iters, void *stream);
+
+/* ---- batch inversion -------------------------------------------------------
+ * out[i] = FieldConfig::inv(x[i]) (crypto_bigint_monty.rs:223-237,
+ * boxed_monty.rs:273-284, const_monty.rs:277-283) for every i, computed with
+ * Montgomery's trick.  Where the reference returns None (x[i] == 0, or not
+ * invertible for a composite modulus) out[i] = 0 and zero_flags[i] = 1;
+ * elsewhere zero_flags[i] = 0.  zero_flags (n bytes, device) may be NULL.
+ * `workspace` is device scratch of fpgpu_batch_inv_workspace_bytes(ctx, n) bytes. */
+size_t fpgpu_batch_inv_workspace_bytes(const fpgpu_ctx *ctx, size_t n);
+int fpgpu_batch_inv_dev(const fpgpu_ctx *ctx, const void *x, void *out, uint8_t *zero_flags, size_t n,
+                        void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- dense matrix products over DenseRowMatrix<T> (src/matrix.rs:135-164) --
+ * y[i] = sum_j mul(A[i*cols + j], x[j]): the SemiringConfig::sum_refs fold
+ * (src/semiring.rs:213-226) of monty_mul over DenseRowMatrix::as_rows().
+ * A is rows*cols elements row-major; x has cols, y has rows elements. */
+int fpgpu_matvec_dev(const fpgpu_ctx *ctx, const void *A, size_t rows, size_t cols, const void *x,
+                     void *y, void *stream);
+/* C[i*n + j] = sum_l mul(A[i*k + l], B[l*n + j]); A is m x k, B is k x n, C is m x n. */
+int fpgpu_matmul_dev(const fpgpu_ctx *ctx, const void *A, const void *B, void *C, size_t m, size_t k,
+                     size_t n, void *stream);
+
+/* ---- synthetic inputs -------------------------------
+ * Fills `out` with n uniform elements in [0, p): word l of element i is
+ * splitmix64(seed ^ (i*n64 + l)), top word masked to bitlen(p), minus p once if >= p.
+ * Identical to the host generator in bench.py / tests. */
+int fpgpu_fill_random_dev(const fpgpu_ctx *ctx, void *out, size_t n, uint64_t seed, void *stream);
+
+/* ---- host-buffer convenience calls (synchronous; H2D, kernel, D2H) -------- */
+int fpgpu_mul(const fpgpu_ctx *ctx, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t n);
+int fpgpu_sqr(const fpgpu_ctx *ctx, const uint64_t *a, uint64_t *out, size_t n);
+int fpgpu_add(const fpgpu_ctx *ctx, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t n);
+int fpgpu_sub(const fpgpu_ctx *ctx, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t n);
+int fpgpu_neg(const fpgpu_ctx *ctx, const uint64_t *a, uint64_t *out, size_t n);
+int fpgpu_to_mont(const fpgpu_ctx *ctx, const uint64_t *a, uint64_t *out, size_t n);
+int fpgpu_from_mont(const fpgpu_ctx *ctx, const uint64_t *a, uint64_t *out, size_t n);
+int fpgpu_mul_chain(const fpgpu_ctx *ctx, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t n,
+                    uint32_t iters);
+int fpgpu_batch_inv(const fpgpu_ctx *ctx, const uint64_t *x, uint64_t *out, uint8_t *zero_flags, size_t n);
+int fpgpu_matvec(const fpgpu_ctx *ctx, const uint64_t *A, size_t rows, size_t cols, const uint64_t *x,
+                 uint64_t *y);
+int fpgpu_matmul(const fpgpu_ctx *ctx, const uint64_t *A, const uint64_t *B, uint64_t *C, size_t m,
+                 size_t k, size_t n);
+
+/* ---- diagnostics ----------------------------------------------------------- */
+const char *fpgpu_last_error_string(void); /* thread-local, never NULL */
+int fpgpu_device_count(void);              /* gfx950 devices visible to this process */
+const char *fpgpu_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FPGPU_H */

@@ -32,7 +32,7 @@ FIELDS = {
     "p64_ref_tests": (0x8BAC0006D9927ABB, 1),           # crypto_bigint_monty.rs:619
     "secp256k1_p": (2**256 - 2**32 - 977, 4),            # crypto_bigint_monty.rs:488-495
     "bench_120bit": (0x860995AE68FC80E1B1BD1E39D54B33, 4),  # benches/const_monty_field_benches.rs:9-13
-    "odd_composite_128": ((2**127 - 1) * 3, 2),          # non-prime odd modulus: inv must report None for gcd != 1
+    "odd_composite_128": ((2**107 - 1) * 3, 2),          # non-prime odd modulus: inv must report None for gcd != 1
 }
 
 
@@ -57,6 +57,7 @@ def edge_values(p, n64):
 
 
 def gen_field(name, p, n64, rng):
+    assert p % 2 == 1 and p < (1 << (64 * n64)), name
     R = 1 << (64 * n64)
     Ri = pow(R, -1, p)
     inv64 = (-pow(p, -1, 1 << 64)) % (1 << 64)
