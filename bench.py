@@ -1,0 +1,303 @@
+#!/usr/bin/env python3
+"""bench.py -- MI355X benchmark of the prime-field Montgomery hot path.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line
+on rank 0.  For N > 1 it is launched under torch.distributed.run, one rank per GPU.
+
+Headline workload (BASELINE.json configs[1]): ConstMontyField 256-bit (BN254 Fr)
+batched Montgomery multiplication over 2^28 HBM-resident elements per GPU.  A "step"
+is one pass `out[i] = mul(a[i], b[i])` over the whole batch; inputs are synthetic
+uniform field elements generated on the device and are resident
+in HBM before the timed region.  Elementwise batches shard across GPUs with no
+data-path collective (weak scaling: every rank owns its own 2^28 elements).
+
+The same line carries:
+  roofline     -- the mul kernel against the HBM roofline (96 algorithmic bytes per
+                  element: two 32-byte operands read, one 32-byte result written),
+                  launch duration measured live with HIP events on the launch stream.
+  cpu_baseline -- the CPU restatement of the reference path (oracle/, kind "port")
+                  timed on this box's host cores on a bounded sample (2^20-element
+                  batches = BASELINE.json configs[0] shape).
+  extra        -- sqr / add / sub over the same batch, the register-resident dependent
+                  mul chain (VALU-bound Gmul/s), BLS12-381 batch inversion and the
+                  256-bit mat-vec (row-sharded, RCCL all-gather of y when N > 1).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+VALU_MAD_PEAK_TOPS = 39.3       # 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz v_mad_u64_u32 lane-ops/s (measured 36.5)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--log2n", type=int, default=28, help="elements per GPU = 2^log2n")
+    ap.add_argument("--workload", default="mul", choices=["mul", "sqr", "add", "sub", "matvec", "batch_inv"])
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary measurements")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--matvec-log2", type=int, default=15, help="mat-vec is 2^k x 2^k")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import crypto_primitives_amd as cpa
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    distributed = world > 1
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    def barrier():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(x):
+        if not distributed:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    n = 1 << args.log2n
+    f = cpa.MontyField(cpa.BN254_FR, 4)
+    a = f.random_dev(n, 0x9E3779B97F4A7C15 ^ (2 + 1000 * rank))
+    b = f.random_dev(n, 0x9E3779B97F4A7C15 ^ (3 + 1000 * rank))
+    out = f.alloc(n)
+
+    ops = {
+        "mul": (lambda: f.mul_dev(a, b, out), 96),
+        "sqr": (lambda: f.sqr_dev(a, out), 64),
+        "add": (lambda: f.add_dev(a, b, out), 96),
+        "sub": (lambda: f.sub_dev(a, b, out), 96),
+    }
+
+    def time_steps(fn, steps, warmup):
+        """Returns (wall seconds for `steps` steps, max over ranks; mean launch duration in s from
+        HIP events recorded on the launch stream)."""
+        for _ in range(warmup):
+            fn()
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        barrier()
+        t0 = time.perf_counter()
+        for e0, e1 in evs:
+            e0.record()
+            fn()
+            e1.record()
+        barrier()
+        wall = time.perf_counter() - t0
+        kern = sum(e0.elapsed_time(e1) for e0, e1 in evs) / steps * 1e-3
+        return max_over_ranks(wall), max_over_ranks(kern)
+
+    result = {}
+    extra = {}
+
+    # ---------------- primary workload ------------------------------------------------
+    if args.workload in ops:
+        fn, bytes_per = ops[args.workload]
+        wall, kern = time_steps(fn, args.steps, args.warmup)
+        total_elems = n * world * args.steps
+        value = total_elems / wall / 1e9
+        # spot-check a strided sample of the last pass against the CPU oracle
+        verified = None
+        if rank == 0:
+            try:
+                from oracle.fp_oracle import Oracle
+                o = Oracle(cpa.BN254_FR, 4)
+                idx = torch.arange(0, n, max(1, n // 4096), device="cuda")
+                sa = a[idx].cpu().numpy().view(np.uint64)
+                sb = b[idx].cpu().numpy().view(np.uint64)
+                exp = {"mul": o.mul, "add": o.add, "sub": o.sub}.get(args.workload)
+                exp = exp(sa, sb) if exp else o.sqr(sa)
+                verified = bool(np.array_equal(out[idx].cpu().numpy().view(np.uint64), exp))
+            except Exception as e:  # oracle missing: report, do not fake
+                verified = f"unchecked: {e}"
+        unit = {"mul": "Gmul/s", "sqr": "Gsqr/s", "add": "Gadd/s", "sub": "Gsub/s"}[args.workload]
+        achieved = bytes_per * n / kern / 1e9
+        result = {
+            "metric": "256-bit Montgomery %s (BN254 Fr, HBM-resident batch)" % unit,
+            "value": value, "unit": unit,
+            "per_gpu": value / world,
+            "ms_per_step": wall / args.steps * 1e3,
+            "config": {"workload": "BN254 Fr 256-bit batched %s over 2^%d HBM-resident elements per GPU "
+                                   "(BASELINE.json configs[1])" % (args.workload, args.log2n),
+                       "elements_per_gpu": n, "limbs64": 4, "parallelism": "shard%d" % world},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "kernel": "k_elementwise<8,%s>" % args.workload, "bytes_per_element": bytes_per,
+                         "kernel_ms": kern * 1e3},
+            "verified_vs_oracle": verified,
+        }
+    elif args.workload == "matvec":
+        result = bench_matvec(args, f, world, rank, distributed, time_steps, primary=True)
+    elif args.workload == "batch_inv":
+        result = bench_batch_inv(args, world, rank, time_steps, primary=True)
+
+    # ---------------- secondary measurements ------------------------------------------
+    if not args.no_extra:
+        ksteps = max(3, min(args.steps, 10))
+        for name, (fn, bytes_per) in ops.items():
+            if name == args.workload:
+                continue
+            wall, kern = time_steps(fn, ksteps, 1)
+            extra[name] = {"Gelem_per_s": n * world * ksteps / wall / 1e9, "kernel_ms": kern * 1e3,
+                           "hbm_GBps_per_gpu": bytes_per * n / kern / 1e9,
+                           "hbm_frac": bytes_per * n / kern / 1e9 / HBM_PEAK_GBPS}
+        # register-resident dependent chain: the VALU-bound Gmul/s ("Mul assign" shape)
+        nchain, iters = 1 << 22, 256
+        wall, kern = time_steps(lambda: f.mul_chain_dev(a[:nchain], b[:nchain], out[:nchain], iters), 5, 1)
+        gmul = nchain * iters / kern / 1e9
+        extra["mul_chain"] = {"Gmul_per_s_per_gpu": gmul, "elements": nchain, "iters": iters,
+                              "valu_mad_Tops": gmul * 136 / 1e3, "valu_mad_peak_Tops": VALU_MAD_PEAK_TOPS,
+                              "valu_frac_vs_136_mads": gmul * 136 / 1e3 / VALU_MAD_PEAK_TOPS}
+        if args.workload != "batch_inv":
+            extra["batch_inv_bls12_381"] = bench_batch_inv(args, world, rank, time_steps, primary=False)
+        if args.workload != "matvec":
+            extra["matvec_bn254"] = bench_matvec(args, f, world, rank, distributed, time_steps, primary=False)
+
+    # ---------------- CPU baseline (rank 0, N = 1 only) --------------------------------
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu:
+        cpu = cpu_baseline()
+
+    if rank == 0:
+        line = {
+            "metric": result.get("metric"), "value": result.get("value"), "unit": result.get("unit"),
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": result.get("ms_per_step"), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u32 limbs (8 x 32-bit per 256-bit element, v_mad_u64_u32)",
+            "data": "synthetic uniform field elements generated on device (SplitMix64 counter RNG)",
+            "config": result.get("config"), "per_gpu": result.get("per_gpu"),
+            "roofline": result.get("roofline"), "cpu_baseline": cpu,
+            "verified_vs_oracle": result.get("verified_vs_oracle"), "extra": extra,
+        }
+        print(json.dumps(line), flush=True)
+    if distributed:
+        dist.destroy_process_group()
+
+
+def bench_batch_inv(args, world, rank, time_steps, primary):
+    """BASELINE.json configs[2]: BLS12-381 Fq (384-bit precision) batch inversion over 2^24
+    elements, sharded: each rank inverts its own 2^24/world slice (strong scaling)."""
+    import torch
+    import crypto_primitives_amd as cpa
+    fq = cpa.MontyField(cpa.BLS12_381_FQ, 6)
+    total = 1 << 24
+    n = total // world
+    x = fq.random_dev(n, 0xB15 ^ (7 + 1000 * rank))
+    out = fq.alloc(n)
+    flags = torch.empty(n, dtype=torch.uint8, device="cuda")
+    ws = torch.empty(fq.inv_workspace_bytes(n), dtype=torch.uint8, device="cuda")
+    steps = args.steps if primary else 5
+    wall, kern = time_steps(lambda: fq.inv_dev(x, out, flags, ws), steps, 1)
+    # property check: x * inv(x) == one wherever x != 0
+    chk = fq.alloc(n)
+    fq.mul_dev(x, out, chk)
+    import numpy as np
+    one = torch.from_numpy(fq.one_words.view(np.int64)).cuda()
+    ok = bool(torch.equal(chk[flags == 0], one.expand(int((flags == 0).sum()), 6)))
+    res = {"Ginv_per_s": total * steps / wall / 1e9, "ms_per_batch": wall / steps * 1e3,
+           "elements_total": total, "algorithmic_GBps_per_gpu": 96 * n / kern / 1e9,
+           "x_times_inv_is_one": ok}
+    if primary:
+        res = {"metric": "BLS12-381 Fq batch inversion Ginv/s", "value": res["Ginv_per_s"], "unit": "Ginv/s",
+               "per_gpu": res["Ginv_per_s"] / world, "ms_per_step": res["ms_per_batch"],
+               "config": {"workload": "BLS12-381 Fq 384-bit batch inversion over 2^24 elements "
+                                      "(BASELINE.json configs[2])", "parallelism": "shard%d" % world},
+               "roofline": {"bound": "hbm", "achieved": 96 * n / kern / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                            "frac": 96 * n / kern / 1e9 / HBM_PEAK_GBPS, "traffic": None},
+               "verified_vs_oracle": ok}
+    return res
+
+
+def bench_matvec(args, f, world, rank, distributed, time_steps, primary):
+    """BASELINE.json configs[3]: 256-bit Fp dense mat-vec, rows sharded across ranks,
+    y reassembled with an RCCL all-gather (the only collective on the path)."""
+    import torch
+    import torch.distributed as dist
+    dim = 1 << args.matvec_log2
+    rows = dim // world
+    A = f.random_dev(rows * dim, 0xA ^ (11 + 1000 * rank))
+    x = f.random_dev(dim, 0xC0FFEE)           # same x on every rank (replicated operand)
+    y_local = f.alloc(rows)
+    y = f.alloc(dim) if distributed else y_local
+
+    def step():
+        f.matvec_dev(A, rows, dim, x, y_local)
+        if distributed:
+            dist.all_gather_into_tensor(y, y_local)
+
+    steps = args.steps if primary else 5
+    wall, kern = time_steps(step, steps, 1)
+    elems = dim * dim
+    res = {"matrix_elems_per_s": elems * steps / wall, "ms_per_matvec": wall / steps * 1e3,
+           "dim": dim, "hbm_GBps_per_gpu": 32.0 * (rows * dim + dim + rows) / kern / 1e9,
+           "hbm_frac": 32.0 * (rows * dim + dim + rows) / kern / 1e9 / HBM_PEAK_GBPS}
+    if primary:
+        res = {"metric": "256-bit Fp mat-vec matrix elems/s", "value": res["matrix_elems_per_s"],
+               "unit": "elems/s", "per_gpu": res["matrix_elems_per_s"] / world,
+               "ms_per_step": res["ms_per_matvec"],
+               "config": {"workload": "BN254 Fr 2^%d x 2^%d dense mat-vec, row-sharded "
+                                      "(BASELINE.json configs[3])" % (args.matvec_log2, args.matvec_log2),
+                          "parallelism": "rowshard%d+allgather" % world},
+               "roofline": {"bound": "hbm", "achieved": res["hbm_GBps_per_gpu"], "peak": HBM_PEAK_GBPS,
+                            "unit": "GB/s", "frac": res["hbm_frac"], "traffic": None, "kernel": "k_matvec<8>"},
+               "verified_vs_oracle": None}
+    return res
+
+
+def cpu_baseline():
+    """The CPU restatement of the reference's path (oracle/, "port"), timed on this box's host
+    cores: 2^20-element BN254 Fr batches (BASELINE.json configs[0] shape), repeated for a
+    bounded ~10 s, all OpenMP threads the box grants."""
+    import numpy as np
+    from oracle.fp_oracle import Oracle, max_threads
+    import crypto_primitives_amd as cpa
+    o = Oracle(cpa.BN254_FR, 4)
+    n = 1 << 20
+    rng = np.random.default_rng(1)
+    a = rng.integers(0, 1 << 62, size=(n, 4), dtype=np.uint64)
+    b = rng.integers(0, 1 << 62, size=(n, 4), dtype=np.uint64)
+    a[:, 3] &= (1 << 60) - 1
+    b[:, 3] &= (1 << 60) - 1
+    threads = max_threads()
+    o.mul(a, b, threads=0)  # warm up the thread pool
+    reps, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < 8.0:
+        o.mul(a, b, threads=0)
+        reps += 1
+    dt = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    o.mul(a[: n // 8], b[: n // 8], threads=1)
+    single = (n // 8) / (time.perf_counter() - t1) / 1e9
+    return {"value": reps * n / dt / 1e9, "unit": "Gmul/s", "cores": threads, "kind": "port",
+            "sample": "%d passes of a 2^20-element BN254 Fr mul batch (C restatement of monty_mul, "
+                      "-O3, OpenMP static chunks); single-thread rate %.4f Gmul/s" % (reps, single),
+            "single_thread_Gmul_per_s": single}
+
+
+if __name__ == "__main__":
+    main()

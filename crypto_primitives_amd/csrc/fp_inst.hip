@@ -1,0 +1,124 @@
+// fp_inst.hip -- instantiates every kernel launcher for ONE limb count (-DFPGPU_N=N).
+#include "fp_kernels.cuh"
+#include "fp_launch.hpp"
+
+#ifndef FPGPU_N
+#error "compile with -DFPGPU_N=<number of 32-bit limbs>"
+#endif
+
+namespace fpgpu {
+
+template <int N>
+static FpParams<N> make_params(const fpgpu_ctx* c) {
+    FpParams<N> P;
+    for (int i = 0; i < N / 2; i++) {
+        P.m[2 * i] = (uint32_t)c->modulus[i];
+        P.m[2 * i + 1] = (uint32_t)(c->modulus[i] >> 32);
+        P.r2[2 * i] = (uint32_t)c->r2[i];
+        P.r2[2 * i + 1] = (uint32_t)(c->r2[i] >> 32);
+        P.one[2 * i] = (uint32_t)c->one[i];
+        P.one[2 * i + 1] = (uint32_t)(c->one[i] >> 32);
+    }
+    P.n0inv = (uint32_t)c->mod_neg_inv;
+    P.top_mask = (uint32_t)c->top_mask;
+    P.top_mask_hi = (uint32_t)(c->top_mask >> 32);
+    return P;
+}
+
+template <int N, int OP>
+static void launch_ew(const fpgpu_ctx* ctx, const void* a, const void* b, void* out, size_t n, hipStream_t s) {
+    hipLaunchKernelGGL((k_elementwise<N, OP>), dim3(grid_for(n)), dim3(kBlock), 0, s, (const uint32_t*)a,
+                       (const uint32_t*)b, (uint32_t*)out, n, make_params<N>(ctx));
+}
+
+template <int N>
+void Launch<N>::elementwise(int op, const fpgpu_ctx* ctx, const void* a, const void* b, void* out, size_t n,
+                            hipStream_t s) {
+    switch (op) {
+        case OP_MUL: launch_ew<N, OP_MUL>(ctx, a, b, out, n, s); break;
+        case OP_SQR: launch_ew<N, OP_SQR>(ctx, a, b, out, n, s); break;
+        case OP_ADD: launch_ew<N, OP_ADD>(ctx, a, b, out, n, s); break;
+        case OP_SUB: launch_ew<N, OP_SUB>(ctx, a, b, out, n, s); break;
+        case OP_NEG: launch_ew<N, OP_NEG>(ctx, a, b, out, n, s); break;
+        case OP_TO_MONT: launch_ew<N, OP_TO_MONT>(ctx, a, b, out, n, s); break;
+        case OP_FROM_MONT: launch_ew<N, OP_FROM_MONT>(ctx, a, b, out, n, s); break;
+        default: break;
+    }
+}
+
+template <int N>
+void Launch<N>::mul_chain(const fpgpu_ctx* ctx, const void* a, const void* b, void* out, size_t n, uint32_t iters,
+                          hipStream_t s) {
+    hipLaunchKernelGGL((k_mul_chain<N>), dim3(grid_for(n)), dim3(kBlock), 0, s, (const uint32_t*)a,
+                       (const uint32_t*)b, (uint32_t*)out, n, iters, make_params<N>(ctx));
+}
+
+template <int N>
+void Launch<N>::batch_inv(const fpgpu_ctx* ctx, const void* x, void* out, uint8_t* flags, size_t n, char* ws,
+                          hipStream_t s) {
+    const InvPlan p = make_inv_plan(ctx->n64, n);
+    const FpParams<N> P = make_params<N>(ctx);
+    const size_t tile = (size_t)kBlock * kInvC;
+    auto X = [&](int l) -> const uint32_t* { return l == 0 ? (const uint32_t*)x : (const uint32_t*)(ws + p.x_off[l]); };
+    auto O = [&](int l) -> uint32_t* { return l == 0 ? (uint32_t*)out : (uint32_t*)(ws + p.o_off[l]); };
+    uint8_t* poisoned = (uint8_t*)(ws + p.poison_off);
+    // up-sweeps
+    for (int l = 0; l < p.levels; l++) {
+        int blocks = (int)((p.count[l] + tile - 1) / tile);
+        uint32_t* totals = (uint32_t*)(ws + p.x_off[l + 1]);
+        if (l == 0)
+            hipLaunchKernelGGL((k_binv_up<N, kInvC, true>), dim3(blocks), dim3(kBlock), 0, s, X(0), O(0), totals,
+                               flags, p.count[0], P);
+        else
+            hipLaunchKernelGGL((k_binv_up<N, kInvC, false>), dim3(blocks), dim3(kBlock), 0, s, X(l), O(l), totals,
+                               (uint8_t*)nullptr, p.count[l], P);
+    }
+    // top: exact inverses of the remaining totals, in place
+    {
+        size_t c = p.count[p.levels];
+        int blocks = (int)((c + kBlock - 1) / kBlock);
+        hipLaunchKernelGGL((k_binv_top<N>), dim3(blocks), dim3(kBlock), 0, s, (uint32_t*)(ws + p.x_off[p.levels]),
+                           poisoned, c, P);
+    }
+    // down-sweeps
+    for (int l = p.levels - 1; l >= 0; l--) {
+        int blocks = (int)((p.count[l] + tile - 1) / tile);
+        const uint32_t* inv_totals =
+            (l + 1 == p.levels) ? (const uint32_t*)(ws + p.x_off[l + 1]) : (const uint32_t*)O(l + 1);
+        if (l == 0)
+            hipLaunchKernelGGL((k_binv_down<N, kInvC, true>), dim3(blocks), dim3(kBlock), 0, s, X(0), O(0),
+                               inv_totals, p.count[0], P);
+        else
+            hipLaunchKernelGGL((k_binv_down<N, kInvC, false>), dim3(blocks), dim3(kBlock), 0, s, X(l), O(l),
+                               inv_totals, p.count[l], P);
+    }
+    // composite-modulus safety net (a no-op unless a top-level total was not invertible)
+    hipLaunchKernelGGL((k_binv_fallback<N, kInvC>), dim3(grid_for(n)), dim3(kBlock), 0, s, (const uint32_t*)x,
+                       (uint32_t*)out, flags, poisoned, n, p.levels, P);
+}
+
+template <int N>
+void Launch<N>::matvec(const fpgpu_ctx* ctx, const void* A, size_t rows, size_t cols, const void* x, void* y,
+                       hipStream_t s) {
+    int grid = (int)(rows < 65536 ? rows : 65536);
+    hipLaunchKernelGGL((k_matvec<N>), dim3(grid), dim3(kBlock), 0, s, (const uint32_t*)A, (const uint32_t*)x,
+                       (uint32_t*)y, rows, cols, make_params<N>(ctx));
+}
+
+template <int N>
+void Launch<N>::matmul(const fpgpu_ctx* ctx, const void* A, const void* B, void* C, size_t m, size_t k, size_t n,
+                       hipStream_t s) {
+    size_t gx = (n + kMMTile - 1) / kMMTile, gy = (m + kMMTile - 1) / kMMTile;
+    hipLaunchKernelGGL((k_matmul<N>), dim3((unsigned)gx, (unsigned)gy), dim3(kMMTile * kMMTile), 0, s,
+                       (const uint32_t*)A, (const uint32_t*)B, (uint32_t*)C, m, k, n, make_params<N>(ctx));
+}
+
+template <int N>
+void Launch<N>::fill_random(const fpgpu_ctx* ctx, void* out, size_t n, uint64_t seed, hipStream_t s) {
+    hipLaunchKernelGGL((k_fill_random<N>), dim3(grid_for(n)), dim3(kBlock), 0, s, (uint32_t*)out, n, seed,
+                       make_params<N>(ctx));
+}
+
+template struct Launch<FPGPU_N>;
+
+}  // namespace fpgpu

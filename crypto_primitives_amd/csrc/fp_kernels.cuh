@@ -3,12 +3,10 @@
 // lists algorithmic bytes per element and the roofline that bounds each.
 #pragma once
 #include "fp_device.cuh"
+#include "fp_launch.hpp"
 
 namespace fpgpu {
 
-enum Op : int { OP_MUL = 0, OP_SQR = 1, OP_ADD = 2, OP_SUB = 3, OP_NEG = 4, OP_TO_MONT = 5, OP_FROM_MONT = 6 };
-
-constexpr int kBlock = 256;
 
 // ---- elementwise: out[i] = op(a[i], b[i]) ------------------------------------------
 // One element per lane per iteration, grid-stride.  Lane i of a wave reads its
@@ -355,7 +353,6 @@ __global__ __launch_bounds__(kBlock) void k_matvec(const uint32_t* __restrict__ 
 // 16 x 16 outputs per workgroup, one per lane; K walked in 16-wide tiles staged in
 // LDS.  First correct version; the register-tiled lazy-reduction variant for the
 // single-limb case replaces it in a later round.
-constexpr int kMMTile = 16;
 template <int N>
 __global__ __launch_bounds__(kMMTile* kMMTile) void k_matmul(const uint32_t* __restrict__ A,
                                                              const uint32_t* __restrict__ B,

@@ -1,0 +1,66 @@
+// fp_launch.hpp -- per-limb-count kernel launchers.  Each limb count N is compiled in
+// its own translation unit (fp_inst.hip with -DFPGPU_N=N) so the build parallelises;
+// fpgpu_api.hip only sees these declarations.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/fpgpu.h"
+
+struct fpgpu_ctx {
+    uint32_t n64;
+    uint64_t modulus[FPGPU_MAX_N64];
+    uint64_t one[FPGPU_MAX_N64];
+    uint64_t r2[FPGPU_MAX_N64];
+    uint64_t mod_neg_inv;
+    uint64_t top_mask;  // significant bits of the top word of the modulus
+};
+
+namespace fpgpu {
+
+enum Op : int { OP_MUL = 0, OP_SQR = 1, OP_ADD = 2, OP_SUB = 3, OP_NEG = 4, OP_TO_MONT = 5, OP_FROM_MONT = 6 };
+
+constexpr int kBlock = 256;   // threads per workgroup of every streaming kernel (4 waves)
+constexpr int kMMTile = 16;   // k_matmul output tile edge
+
+// Batch-inversion level plan (shared by the workspace-size query and the launcher).
+constexpr int kInvC = 8;          // chain length per lane
+constexpr size_t kInvTop = 1024;  // stop recursing when this few totals remain
+constexpr int kInvMaxLevels = 16;
+struct InvPlan {
+    int levels = 0;                         // number of up-sweeps
+    size_t count[kInvMaxLevels + 1] = {0};  // count[0] = n, count[l+1] = chains at level l
+    size_t x_off[kInvMaxLevels + 1] = {0};  // byte offset of X_l (l >= 1) in the workspace
+    size_t o_off[kInvMaxLevels + 1] = {0};  // byte offset of O_l (1 <= l < levels)
+    size_t poison_off = 0;
+    size_t bytes = 0;
+};
+InvPlan make_inv_plan(uint32_t n64, size_t n);
+int grid_for(size_t n);
+
+template <int N>
+struct Launch {
+    static void elementwise(int op, const fpgpu_ctx* ctx, const void* a, const void* b, void* out, size_t n,
+                            hipStream_t s);
+    static void mul_chain(const fpgpu_ctx* ctx, const void* a, const void* b, void* out, size_t n, uint32_t iters,
+                          hipStream_t s);
+    static void batch_inv(const fpgpu_ctx* ctx, const void* x, void* out, uint8_t* flags, size_t n, char* ws,
+                          hipStream_t s);
+    static void matvec(const fpgpu_ctx* ctx, const void* A, size_t rows, size_t cols, const void* x, void* y,
+                       hipStream_t s);
+    static void matmul(const fpgpu_ctx* ctx, const void* A, const void* B, void* C, size_t m, size_t k, size_t n,
+                       hipStream_t s);
+    static void fill_random(const fpgpu_ctx* ctx, void* out, size_t n, uint64_t seed, hipStream_t s);
+};
+
+extern template struct Launch<2>;
+extern template struct Launch<4>;
+extern template struct Launch<6>;
+extern template struct Launch<8>;
+extern template struct Launch<10>;
+extern template struct Launch<12>;
+extern template struct Launch<14>;
+extern template struct Launch<16>;
+
+}  // namespace fpgpu

@@ -12,7 +12,7 @@
 #include <string>
 #include <vector>
 
-#include "fp_kernels.cuh"
+#include "fp_launch.hpp"
 
 using namespace fpgpu;
 
@@ -66,33 +66,7 @@ uint64_t neg_inv64(uint64_t m0) {
 
 }  // namespace
 
-struct fpgpu_ctx {
-    uint32_t n64;
-    uint64_t modulus[FPGPU_MAX_N64];
-    uint64_t one[FPGPU_MAX_N64];
-    uint64_t r2[FPGPU_MAX_N64];
-    uint64_t mod_neg_inv;
-    uint64_t top_mask;  // significant bits of the top word of the modulus
-};
-
-namespace {
-
-template <int N>
-FpParams<N> make_params(const fpgpu_ctx* c) {
-    FpParams<N> P;
-    for (int i = 0; i < N / 2; i++) {
-        P.m[2 * i] = (uint32_t)c->modulus[i];
-        P.m[2 * i + 1] = (uint32_t)(c->modulus[i] >> 32);
-        P.r2[2 * i] = (uint32_t)c->r2[i];
-        P.r2[2 * i + 1] = (uint32_t)(c->r2[i] >> 32);
-        P.one[2 * i] = (uint32_t)c->one[i];
-        P.one[2 * i + 1] = (uint32_t)(c->one[i] >> 32);
-    }
-    P.n0inv = (uint32_t)c->mod_neg_inv;
-    P.top_mask = (uint32_t)c->top_mask;
-    P.top_mask_hi = (uint32_t)(c->top_mask >> 32);
-    return P;
-}
+namespace fpgpu {
 
 int grid_for(size_t n) {
     // HBM-streaming kernels: enough workgroups to fill 256 CUs x 8, grid-stride the
@@ -100,6 +74,31 @@ int grid_for(size_t n) {
     size_t blocks = (n + kBlock - 1) / kBlock;
     return (int)std::min<size_t>(std::max<size_t>(blocks, 1), 16384);
 }
+
+
+InvPlan make_inv_plan(uint32_t n64, size_t n) {
+    InvPlan p;
+    const size_t tile = (size_t)kBlock * kInvC;
+    const size_t esz = (size_t)n64 * 8;
+    p.count[0] = n;
+    // at least one level, so the top always works on chain totals
+    while (p.levels < kInvMaxLevels && (p.levels == 0 || p.count[p.levels] > kInvTop)) {
+        size_t c = p.count[p.levels];
+        p.count[p.levels + 1] = (c / tile) * kBlock + std::min<size_t>(c % tile, kBlock);
+        p.levels++;
+    }
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+    for (int l = 1; l <= p.levels; l++) p.x_off[l] = take(p.count[l] * esz);
+    for (int l = 1; l < p.levels; l++) p.o_off[l] = take(p.count[l] * esz);
+    p.poison_off = take(p.count[p.levels]);
+    p.bytes = off;
+    return p;
+}
+
+}  // namespace fpgpu
+
+namespace {
 
 int check_common(const fpgpu_ctx* ctx, size_t n) {
     if (!ctx) return fail(FPGPU_ERR_SHAPE, "null context");
@@ -132,12 +131,6 @@ int check_ptr(const fpgpu_ctx* ctx, const void* p, const char* name) {
         default: return fail(FPGPU_ERR_UNSUPPORTED, "unsupported limb count");      \
     }
 
-template <int N, int OP>
-void launch_elementwise(const fpgpu_ctx* ctx, const void* a, const void* b, void* out, size_t n, hipStream_t s) {
-    hipLaunchKernelGGL((k_elementwise<N, OP>), dim3(grid_for(n)), dim3(kBlock), 0, s, (const uint32_t*)a,
-                       (const uint32_t*)b, (uint32_t*)out, n, make_params<N>(ctx));
-}
-
 template <int OP>
 int elementwise_dev(const fpgpu_ctx* ctx, const void* a, const void* b, void* out, size_t n, void* stream) {
     CHECK(check_common(ctx, n));
@@ -146,87 +139,8 @@ int elementwise_dev(const fpgpu_ctx* ctx, const void* a, const void* b, void* ou
     if (OP == OP_MUL || OP == OP_ADD || OP == OP_SUB) CHECK(check_ptr(ctx, b, "b"));
     CHECK(check_ptr(ctx, out, "out"));
     hipStream_t s = (hipStream_t)stream;
-    DISPATCH_N64(ctx->n64, launch_elementwise<N, OP>(ctx, a, b, out, n, s));
+    DISPATCH_N64(ctx->n64, Launch<N>::elementwise(OP, ctx, a, b, out, n, s));
     HIP_TRY(hipGetLastError());
-    return FPGPU_OK;
-}
-
-// ---- batch inversion plan -----------------------------------------------------------
-constexpr int kInvC = 8;            // chain length per lane
-constexpr size_t kInvTop = 1024;    // stop recursing when this few totals remain
-constexpr int kInvMaxLevels = 16;
-
-struct InvPlan {
-    int levels = 0;                         // number of up-sweeps
-    size_t count[kInvMaxLevels + 1] = {0};  // count[0] = n, count[l+1] = chains at level l
-    size_t x_off[kInvMaxLevels + 1] = {0};  // byte offset of X_l (l >= 1) in the workspace
-    size_t o_off[kInvMaxLevels + 1] = {0};  // byte offset of O_l (1 <= l < levels)
-    size_t poison_off = 0;
-    size_t bytes = 0;
-};
-
-InvPlan make_inv_plan(uint32_t n64, size_t n) {
-    InvPlan p;
-    const size_t tile = (size_t)kBlock * kInvC;
-    const size_t esz = (size_t)n64 * 8;
-    p.count[0] = n;
-    // at least one level, so the top always works on chain totals
-    while (p.levels < kInvMaxLevels && (p.levels == 0 || p.count[p.levels] > kInvTop)) {
-        size_t c = p.count[p.levels];
-        p.count[p.levels + 1] = (c / tile) * kBlock + std::min<size_t>(c % tile, kBlock);
-        p.levels++;
-    }
-    size_t off = 0;
-    auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
-    for (int l = 1; l <= p.levels; l++) p.x_off[l] = take(p.count[l] * esz);
-    for (int l = 1; l < p.levels; l++) p.o_off[l] = take(p.count[l] * esz);
-    p.poison_off = take(p.count[p.levels]);
-    p.bytes = off;
-    return p;
-}
-
-template <int N>
-int batch_inv_launch(const fpgpu_ctx* ctx, const void* x, void* out, uint8_t* flags, size_t n, char* ws,
-                     hipStream_t s) {
-    const InvPlan p = make_inv_plan(ctx->n64, n);
-    const FpParams<N> P = make_params<N>(ctx);
-    const size_t tile = (size_t)kBlock * kInvC;
-    auto X = [&](int l) -> const uint32_t* { return l == 0 ? (const uint32_t*)x : (const uint32_t*)(ws + p.x_off[l]); };
-    auto O = [&](int l) -> uint32_t* { return l == 0 ? (uint32_t*)out : (uint32_t*)(ws + p.o_off[l]); };
-    uint8_t* poisoned = (uint8_t*)(ws + p.poison_off);
-    // up-sweeps
-    for (int l = 0; l < p.levels; l++) {
-        int blocks = (int)((p.count[l] + tile - 1) / tile);
-        uint32_t* totals = (uint32_t*)(ws + p.x_off[l + 1]);
-        if (l == 0)
-            hipLaunchKernelGGL((k_binv_up<N, kInvC, true>), dim3(blocks), dim3(kBlock), 0, s, X(0), O(0), totals,
-                               flags, p.count[0], P);
-        else
-            hipLaunchKernelGGL((k_binv_up<N, kInvC, false>), dim3(blocks), dim3(kBlock), 0, s, X(l), O(l), totals,
-                               (uint8_t*)nullptr, p.count[l], P);
-    }
-    // top: exact inverses of the remaining totals, in place
-    {
-        size_t c = p.count[p.levels];
-        int blocks = (int)((c + kBlock - 1) / kBlock);
-        hipLaunchKernelGGL((k_binv_top<N>), dim3(blocks), dim3(kBlock), 0, s, (uint32_t*)(ws + p.x_off[p.levels]),
-                           poisoned, c, P);
-    }
-    // down-sweeps
-    for (int l = p.levels - 1; l >= 0; l--) {
-        int blocks = (int)((p.count[l] + tile - 1) / tile);
-        const uint32_t* inv_totals =
-            (l + 1 == p.levels) ? (const uint32_t*)(ws + p.x_off[l + 1]) : (const uint32_t*)O(l + 1);
-        if (l == 0)
-            hipLaunchKernelGGL((k_binv_down<N, kInvC, true>), dim3(blocks), dim3(kBlock), 0, s, X(0), O(0),
-                               inv_totals, p.count[0], P);
-        else
-            hipLaunchKernelGGL((k_binv_down<N, kInvC, false>), dim3(blocks), dim3(kBlock), 0, s, X(l), O(l),
-                               inv_totals, p.count[l], P);
-    }
-    // composite-modulus safety net (a no-op unless a top-level total was not invertible)
-    hipLaunchKernelGGL((k_binv_fallback<N, kInvC>), dim3(grid_for(n)), dim3(kBlock), 0, s, (const uint32_t*)x,
-                       (uint32_t*)out, flags, poisoned, n, p.levels, P);
     return FPGPU_OK;
 }
 
@@ -350,9 +264,7 @@ int fpgpu_mul_chain_dev(const fpgpu_ctx* ctx, const void* a, const void* b, void
     CHECK(check_ptr(ctx, b, "b"));
     CHECK(check_ptr(ctx, out, "out"));
     hipStream_t s = (hipStream_t)stream;
-    DISPATCH_N64(ctx->n64, hipLaunchKernelGGL((k_mul_chain<N>), dim3(grid_for(n)), dim3(kBlock), 0, s,
-                                               (const uint32_t*)a, (const uint32_t*)b, (uint32_t*)out, n, iters,
-                                               make_params<N>(ctx)));
+    DISPATCH_N64(ctx->n64, Launch<N>::mul_chain(ctx, a, b, out, n, iters, s));
     HIP_TRY(hipGetLastError());
     return FPGPU_OK;
 }
@@ -373,7 +285,7 @@ int fpgpu_batch_inv_dev(const fpgpu_ctx* ctx, const void* x, void* out, uint8_t*
     if (workspace_bytes < fpgpu_batch_inv_workspace_bytes(ctx, n))
         return fail(FPGPU_ERR_SHAPE, "batch_inv: workspace too small");
     hipStream_t s = (hipStream_t)stream;
-    DISPATCH_N64(ctx->n64, batch_inv_launch<N>(ctx, x, out, zero_flags, n, (char*)workspace, s));
+    DISPATCH_N64(ctx->n64, Launch<N>::batch_inv(ctx, x, out, zero_flags, n, (char*)workspace, s));
     HIP_TRY(hipGetLastError());
     return FPGPU_OK;
 }
@@ -389,9 +301,7 @@ int fpgpu_matvec_dev(const fpgpu_ctx* ctx, const void* A, size_t rows, size_t co
         CHECK(check_ptr(ctx, x, "x"));
     }
     hipStream_t s = (hipStream_t)stream;
-    int grid = (int)std::min<size_t>(rows, 65536);
-    DISPATCH_N64(ctx->n64, hipLaunchKernelGGL((k_matvec<N>), dim3(grid), dim3(kBlock), 0, s, (const uint32_t*)A,
-                                               (const uint32_t*)x, (uint32_t*)y, rows, cols, make_params<N>(ctx)));
+    DISPATCH_N64(ctx->n64, Launch<N>::matvec(ctx, A, rows, cols, x, y, s));
     HIP_TRY(hipGetLastError());
     return FPGPU_OK;
 }
@@ -408,9 +318,7 @@ int fpgpu_matmul_dev(const fpgpu_ctx* ctx, const void* A, const void* B, void* C
     size_t gx = (n + kMMTile - 1) / kMMTile, gy = (m + kMMTile - 1) / kMMTile;
     if (gy > 65535 || gx > ((size_t)1 << 31) - 1) return fail(FPGPU_ERR_SHAPE, "matrix too large");
     hipStream_t s = (hipStream_t)stream;
-    DISPATCH_N64(ctx->n64, hipLaunchKernelGGL((k_matmul<N>), dim3((unsigned)gx, (unsigned)gy), dim3(kMMTile * kMMTile),
-                                               0, s, (const uint32_t*)A, (const uint32_t*)B, (uint32_t*)C, m, k, n,
-                                               make_params<N>(ctx)));
+    DISPATCH_N64(ctx->n64, Launch<N>::matmul(ctx, A, B, C, m, k, n, s));
     HIP_TRY(hipGetLastError());
     return FPGPU_OK;
 }
@@ -420,8 +328,7 @@ int fpgpu_fill_random_dev(const fpgpu_ctx* ctx, void* out, size_t n, uint64_t se
     if (n == 0) return FPGPU_OK;
     CHECK(check_ptr(ctx, out, "out"));
     hipStream_t s = (hipStream_t)stream;
-    DISPATCH_N64(ctx->n64, hipLaunchKernelGGL((k_fill_random<N>), dim3(grid_for(n)), dim3(kBlock), 0, s,
-                                               (uint32_t*)out, n, seed, make_params<N>(ctx)));
+    DISPATCH_N64(ctx->n64, Launch<N>::fill_random(ctx, out, n, seed, s));
     HIP_TRY(hipGetLastError());
     return FPGPU_OK;
 }
