@@ -274,7 +274,7 @@ def cpu_baseline():
     cores: 2^20-element BN254 Fr batches (BASELINE.json configs[0] shape), repeated for a
     bounded ~10 s, all OpenMP threads the box grants."""
     import numpy as np
-    from oracle.fp_oracle import Oracle, max_threads
+    from oracle.fp_oracle import Oracle
     import crypto_primitives_amd as cpa
     o = Oracle(cpa.BN254_FR, 4)
     n = 1 << 20
@@ -283,11 +283,14 @@ def cpu_baseline():
     b = rng.integers(0, 1 << 62, size=(n, 4), dtype=np.uint64)
     a[:, 3] &= (1 << 60) - 1
     b[:, 3] &= (1 << 60) - 1
-    threads = max_threads()
-    o.mul(a, b, threads=0)  # warm up the thread pool
+    # the box's CPU share (OMP_NUM_THREADS is 16 for one GPU); set explicitly because
+    # libraries loaded earlier in this process may have lowered OpenMP's default
+    avail = len(os.sched_getaffinity(0))
+    threads = max(1, min(int(os.environ.get("OMP_NUM_THREADS") or avail), avail))
+    o.mul(a, b, threads=threads)  # warm up the thread pool
     reps, t0 = 0, time.perf_counter()
     while time.perf_counter() - t0 < 8.0:
-        o.mul(a, b, threads=0)
+        o.mul(a, b, threads=threads)
         reps += 1
     dt = time.perf_counter() - t0
     t1 = time.perf_counter()

@@ -1,0 +1,79 @@
+"""CPU: the C-ABI shared library loads and exports every symbol include/fpgpu.h
+declares; context set-up (host code) matches the golden Montgomery constants; argument
+errors are reported through status codes; with no GPU the batch calls fail loudly
+(there is no CPU fallback)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, array_to_ints, h2i
+
+import crypto_primitives_amd as cpa
+from crypto_primitives_amd import _lib
+
+
+def _declared_functions():
+    src = open(os.path.join(ROOT, "include", "fpgpu.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(fpgpu_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = cpa.load()
+    names = _declared_functions()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(lib, n), f"libfpgpu.so does not export {n}"
+    # and the Python prototypes cover the same set
+    assert sorted(_lib.SIGNATURES) == names
+
+
+def test_ctx_params_match_golden(golden):
+    f = cpa.MontyField(h2i(golden["modulus"]), golden["n64"])
+    assert f.mod_neg_inv == h2i(golden["mod_neg_inv"])
+    assert array_to_ints(f.one_words.reshape(1, -1))[0] == h2i(golden["one"])
+    assert array_to_ints(f.r2_words.reshape(1, -1))[0] == h2i(golden["r2"])
+    assert array_to_ints(f.modulus_words.reshape(1, -1))[0] == h2i(golden["modulus"])
+
+
+def test_invalid_modulus_and_unsupported_width():
+    with pytest.raises(cpa.InvalidModulus):
+        cpa.MontyField(42, 4)          # even: FieldError::InvalidModulus (crypto_bigint_monty.rs:1050-1055)
+    with pytest.raises(cpa.InvalidModulus):
+        cpa.MontyField(0, 1)
+    with pytest.raises(cpa.FpgpuError) as e:
+        cpa.MontyField(3, 9)           # wider than any compiled kernel
+    assert e.value.code == _lib.ERR_UNSUPPORTED
+
+
+def test_argument_checks_need_no_gpu():
+    lib = cpa.load()
+    f = cpa.MontyField(cpa.BN254_FR, 4)
+    # n == 0 is a no-op for every entry point
+    assert lib.fpgpu_mul_dev(f._h, None, None, None, 0, None) == _lib.OK
+    assert lib.fpgpu_mul(f._h, None, None, None, 0) == _lib.OK
+    assert lib.fpgpu_batch_inv(f._h, None, None, None, 0) == _lib.OK
+    # null / misaligned device pointers are rejected before any launch
+    assert lib.fpgpu_mul_dev(f._h, None, None, None, 4, None) == _lib.ERR_SHAPE
+    assert lib.fpgpu_add_dev(f._h, ctypes.c_void_p(8), ctypes.c_void_p(16), ctypes.c_void_p(32), 4, None) == _lib.ERR_SHAPE
+    assert b"misaligned" in lib.fpgpu_last_error_string()
+    assert lib.fpgpu_batch_inv_dev(f._h, ctypes.c_void_p(64), ctypes.c_void_p(64), None, 4, None, 0, None) == _lib.ERR_SHAPE
+    assert lib.fpgpu_mul_dev(None, None, None, None, 4, None) == _lib.ERR_SHAPE
+    # workspace query is pure host arithmetic and grows with n
+    w1 = lib.fpgpu_batch_inv_workspace_bytes(f._h, 1 << 10)
+    w2 = lib.fpgpu_batch_inv_workspace_bytes(f._h, 1 << 20)
+    assert 0 < w1 < w2 < (1 << 20) * 32
+
+
+@pytest.mark.skipif(cpa.load().fpgpu_device_count() > 0, reason="only meaningful without a GPU")
+def test_no_cpu_fallback_without_gpu():
+    f = cpa.MontyField(cpa.BN254_FR, 4)
+    a = np.ones((4, 4), dtype=np.uint64)
+    with pytest.raises(cpa.FpgpuError) as e:
+        f.mul(a, a)
+    assert e.value.code == _lib.ERR_NO_DEVICE
+    with pytest.raises(cpa.FpgpuError):
+        f.inv(a)

@@ -1,0 +1,94 @@
+"""CPU: the C oracle (oracle/fp_oracle.c) against the independent Python-int golden
+vectors (tests/golden/, generator committed).  Bit-exact."""
+import numpy as np
+
+from conftest import array_to_ints, h2i, ints_to_array
+from oracle.fp_oracle import Oracle
+
+
+def _o(g):
+    return Oracle(h2i(g["modulus"]), g["n64"])
+
+
+def test_params(golden):
+    o = _o(golden)
+    assert o.mod_neg_inv == h2i(golden["mod_neg_inv"])
+    assert array_to_ints(o.one.reshape(1, -1))[0] == h2i(golden["one"])
+    assert array_to_ints(o.r2.reshape(1, -1))[0] == h2i(golden["r2"])
+
+
+def test_binary(golden):
+    o, n64 = _o(golden), golden["n64"]
+    a = ints_to_array([h2i(v["a"]) for v in golden["binary"]], n64)
+    b = ints_to_array([h2i(v["b"]) for v in golden["binary"]], n64)
+    assert array_to_ints(o.mul(a, b)) == [h2i(v["mul"]) for v in golden["binary"]]
+    assert array_to_ints(o.mul_boxed(a, b)) == [h2i(v["mul"]) for v in golden["binary"]]
+    assert array_to_ints(o.add(a, b)) == [h2i(v["add"]) for v in golden["binary"]]
+    assert array_to_ints(o.sub(a, b)) == [h2i(v["sub"]) for v in golden["binary"]]
+
+
+def test_unary(golden):
+    o, n64 = _o(golden), golden["n64"]
+    a = ints_to_array([h2i(v["a"]) for v in golden["unary"]], n64)
+    assert array_to_ints(o.neg(a)) == [h2i(v["neg"]) for v in golden["unary"]]
+    assert array_to_ints(o.sqr(a)) == [h2i(v["sqr"]) for v in golden["unary"]]
+    assert array_to_ints(o.to_mont(a)) == [h2i(v["to_mont"]) for v in golden["unary"]]
+    assert array_to_ints(o.from_mont(a)) == [h2i(v["from_mont"]) for v in golden["unary"]]
+    out, flags = o.batch_inv(a)
+    exp = [v["inv"] for v in golden["unary"]]
+    assert list(flags) == [1 if e is None else 0 for e in exp]
+    assert array_to_ints(out) == [0 if e is None else h2i(e) for e in exp]
+
+
+def test_wide(golden):
+    o, n64 = _o(golden), golden["n64"]
+    a = ints_to_array([h2i(v["a"]) for v in golden["to_mont_wide"]], n64)
+    assert array_to_ints(o.to_mont(a)) == [h2i(v["to_mont"]) for v in golden["to_mont_wide"]]
+    a = ints_to_array([h2i(v["a"]) for v in golden["mul_wide_a"]], n64)
+    b = ints_to_array([h2i(v["b"]) for v in golden["mul_wide_a"]], n64)
+    assert array_to_ints(o.mul(a, b)) == [h2i(v["mul"]) for v in golden["mul_wide_a"]]
+    assert array_to_ints(o.mul_boxed(a, b)) == [h2i(v["mul"]) for v in golden["mul_wide_a"]]
+
+
+def test_batch_inv(golden):
+    o, n64 = _o(golden), golden["n64"]
+    for case in golden["batch_inv"]:
+        x = ints_to_array([h2i(v) for v in case["x"]], n64)
+        out, flags = o.batch_inv(x)
+        assert list(flags) == [1 if e is None else 0 for e in case["inv"]]
+        assert array_to_ints(out) == [0 if e is None else h2i(e) for e in case["inv"]]
+
+
+def test_matvec_matmul(golden):
+    o, n64 = _o(golden), golden["n64"]
+    for c in golden["matvec"]:
+        A = ints_to_array([h2i(v) for v in c["A"]], n64)
+        x = ints_to_array([h2i(v) for v in c["x"]], n64)
+        assert array_to_ints(o.matvec(A, c["rows"], c["cols"], x)) == [h2i(v) for v in c["y"]]
+    for c in golden["matmul"]:
+        A = ints_to_array([h2i(v) for v in c["A"]], n64)
+        B = ints_to_array([h2i(v) for v in c["B"]], n64)
+        assert array_to_ints(o.matmul(A, B, c["m"], c["k"], c["n"])) == [h2i(v) for v in c["C"]]
+
+
+def test_cios_and_limbs_variants_agree_on_arbitrary_inputs():
+    """monty_mul (CIOS + masked subtract) and the Boxed path (monty_mul_limbs +
+    sub_assign_mod_with_carry) produce the same words for ANY a, b < R."""
+    import random
+    rng = random.Random(3)
+    for p, n64 in ((0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001, 4),
+                   (0xFFFFFFFF00000001, 1), (2**256 - 2**32 - 977, 4)):
+        o = Oracle(p, n64)
+        R = 1 << (64 * n64)
+        a = ints_to_array([rng.randrange(R) for _ in range(3000)], n64)
+        b = ints_to_array([rng.randrange(R) for _ in range(3000)], n64)
+        assert np.array_equal(o.mul(a, b), o.mul_boxed(a, b))
+
+
+def test_openmp_driver_matches_serial():
+    p, n64 = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001, 4
+    o = Oracle(p, n64)
+    rng = np.random.default_rng(0)
+    a = rng.integers(0, 1 << 60, size=(5000, 4), dtype=np.uint64)
+    b = rng.integers(0, 1 << 60, size=(5000, 4), dtype=np.uint64)
+    assert np.array_equal(o.mul(a, b, threads=1), o.mul(a, b, threads=4))
