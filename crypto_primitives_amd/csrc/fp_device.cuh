@@ -173,6 +173,87 @@ __device__ __forceinline__ void mont_retrieve(uint32_t (&r)[N], const uint32_t (
     }
 }
 
+
+// ---- lazy (unreduced) products for long dot products ---------------------------------
+// prod[0..2N) = sum_{t<T} a[t] * b[t] as a plain 2N-limb integer (product scanning, no
+// reduction).  The caller guarantees the sum fits 2N limbs (T * p^2 < R^2 always holds
+// for the T <= 4 used here when p < R / T; see k_matvec).
+template <int N, int T>
+__device__ __forceinline__ void mul_wide_sum(uint32_t (&prod)[2 * N], const uint32_t (&a)[T][N],
+                                             const uint32_t (&b)[T][N]) {
+    Acc96 acc{0, 0};
+#pragma unroll
+    for (int k = 0; k < 2 * N - 1; k++) {
+        const int lo = k < N ? 0 : k - N + 1;
+        const int hi = k < N ? k : N - 1;
+#pragma unroll
+        for (int t = 0; t < T; t++)
+#pragma unroll
+            for (int i = lo; i <= hi; i++) mac_vv(acc, a[t][i], b[t][k - i]);
+        prod[k] = (uint32_t)acc.lo;
+        acc_shift(acc);
+    }
+    prod[2 * N - 1] = (uint32_t)acc.lo;
+}
+
+// S += prod with the invariant S < p*R kept (S = S_hi*R + S_lo, S_hi < p): the low halves
+// add with a plain carry chain; the high halves add modulo p with that carry folded in.
+// Valid whenever prod < p*R (prod_hi < p): any product of two canonical residues, or a sum
+// of T such products when T*p <= R.
+template <int N>
+__device__ __forceinline__ void wide_acc_add(uint32_t (&S)[2 * N], const uint32_t (&prod)[2 * N],
+                                             const FpParams<N>& P) {
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        uint64_t t = (uint64_t)S[i] + prod[i] + c;
+        S[i] = (uint32_t)t;
+        c = (uint32_t)(t >> 32);
+    }
+    uint32_t w[N], d[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        uint64_t t = (uint64_t)S[N + i] + prod[N + i] + c;
+        w[i] = (uint32_t)t;
+        c = (uint32_t)(t >> 32);
+    }
+    uint32_t bo = sub_limbs_s<N>(d, w, P.m);
+    bool keep_w = c < bo;
+#pragma unroll
+    for (int i = 0; i < N; i++) S[N + i] = keep_w ? w[i] : d[i];
+}
+
+// r = S * R^-1 mod p for a 2N-limb S < p*R (Montgomery reduction + one conditional
+// subtract).  sum_j mont_mul(a_j, b_j) mod p == mont_redc_wide(sum_j a_j*b_j) exactly.
+template <int N>
+__device__ __forceinline__ void mont_redc_wide(uint32_t (&r)[N], const uint32_t (&S)[2 * N], const FpParams<N>& P) {
+    uint32_t u[N], t[N];
+    Acc96 acc{0, 0};
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        acc_add32(acc, S[k]);
+#pragma unroll
+        for (int i = 0; i < k; i++) mac_vs(acc, u[i], P.m[k - i]);
+        u[k] = (uint32_t)acc.lo * P.n0inv;
+        mac_vs(acc, u[k], P.m[0]);
+        acc_shift(acc);
+    }
+#pragma unroll
+    for (int k = N; k < 2 * N; k++) {
+        acc_add32(acc, S[k]);
+#pragma unroll
+        for (int i = k - N + 1; i < N; i++) mac_vs(acc, u[i], P.m[k - i]);
+        t[k - N] = (uint32_t)acc.lo;
+        acc_shift(acc);
+    }
+    uint32_t top = (uint32_t)acc.lo;
+    uint32_t d[N];
+    uint32_t bo = sub_limbs_s<N>(d, t, P.m);
+    bool use_d = (top != 0) | (bo == 0);
+#pragma unroll
+    for (int i = 0; i < N; i++) r[i] = use_d ? d[i] : t[i];
+}
+
 // ---- modular add / sub / neg (crypto-bigint add_mod / sub_mod / neg_mod) -------
 // add: w = a + b; w' = w - p; keep w' unless the subtraction borrowed past the
 // add's carry.  Bit-identical to crypto-bigint's masked form for all inputs.

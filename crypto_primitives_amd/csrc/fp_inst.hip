@@ -1,4 +1,6 @@
 // fp_inst.hip -- instantiates every kernel launcher for ONE limb count (-DFPGPU_N=N).
+#include <cstdlib>
+
 #include "fp_kernels.cuh"
 #include "fp_launch.hpp"
 
@@ -100,9 +102,25 @@ void Launch<N>::batch_inv(const fpgpu_ctx* ctx, const void* x, void* out, uint8_
 template <int N>
 void Launch<N>::matvec(const fpgpu_ctx* ctx, const void* A, size_t rows, size_t cols, const void* x, void* y,
                        hipStream_t s) {
+    // Terms per product-scanning pass: T products may be summed before the wide add only
+    // if T*p <= R, i.e. the modulus leaves log2(T) zero bits at the top of its container.
+    // FPGPU_MATVEC_T overrides (downwards only) for A/B measurements.
+    static const int t_env = [] { const char* e = getenv("FPGPU_MATVEC_T"); return e ? atoi(e) : 0; }();
+    int lz = __builtin_clzll(ctx->modulus[ctx->n64 - 1] | 1);
+    if (ctx->modulus[ctx->n64 - 1] == 0) lz = 64;
+    int T = lz >= 2 ? 4 : (lz >= 1 ? 2 : 1);
+    if (N > 8 && T > 2) T = 2;  // register budget (T = 4 at N = 12 needs 182 VGPRs)
+    if (t_env > 0 && t_env < T) T = t_env;
     int grid = (int)(rows < 65536 ? rows : 65536);
-    hipLaunchKernelGGL((k_matvec<N>), dim3(grid), dim3(kBlock), 0, s, (const uint32_t*)A, (const uint32_t*)x,
-                       (uint32_t*)y, rows, cols, make_params<N>(ctx));
+    const uint32_t* Ap = (const uint32_t*)A;
+    const uint32_t* xp = (const uint32_t*)x;
+    uint32_t* yp = (uint32_t*)y;
+    if (T >= 4)
+        hipLaunchKernelGGL((k_matvec<N, 4>), dim3(grid), dim3(kBlock), 0, s, Ap, xp, yp, rows, cols, make_params<N>(ctx));
+    else if (T >= 2)
+        hipLaunchKernelGGL((k_matvec<N, 2>), dim3(grid), dim3(kBlock), 0, s, Ap, xp, yp, rows, cols, make_params<N>(ctx));
+    else
+        hipLaunchKernelGGL((k_matvec<N, 1>), dim3(grid), dim3(kBlock), 0, s, Ap, xp, yp, rows, cols, make_params<N>(ctx));
 }
 
 template <int N>

@@ -303,28 +303,47 @@ __device__ __forceinline__ void wave_reduce_add(uint32_t (&acc)[N], const FpPara
 }
 
 // ---- dense mat-vec: y[i] = sum_j A[i][j] * x[j] -----------------------------------
-// One workgroup per row; lane t takes columns t, t+256, ... (coalesced 2 KiB per
-// wave-load of A; x is re-read by every row and stays L2-resident), keeps a
-// canonical partial sum, then the block tree-reduces 256 partials with mod_add.
-template <int N>
+// One workgroup per row; lane t takes columns t, t+256, ... (a wave-load of A is 64
+// consecutive elements = 2 KiB contiguous; x is re-read by every row and stays
+// L2-resident).  Lazy reduction: the plain 2N-limb products of T consecutive terms are
+// summed in ONE product-scanning pass (T*N^2 multiply-adds, one set of column shifts),
+// added into a per-lane 2N-limb accumulator kept below p*R (wide_acc_add), and the
+// Montgomery reduction is paid once per lane per row instead of once per matrix
+// element.  T terms may share a pass only when T*p <= R (their sum stays below p*R);
+// the host picks T from the modulus' leading zero bits.  The result is the same
+// canonical residue as the reference's fold of mul and add.
+template <int N, int T>
 __global__ __launch_bounds__(kBlock) void k_matvec(const uint32_t* __restrict__ A, const uint32_t* __restrict__ x,
                                                    uint32_t* __restrict__ y, size_t rows, size_t cols,
                                                    const FpParams<N> P) {
     __shared__ uint32_t part[kBlock / 64][N];
     for (size_t row = blockIdx.x; row < rows; row += gridDim.x) {
-        const uint32_t* Arow = A + row * cols * N;
-        uint32_t acc[N];
+        const uint32_t* __restrict__ Arow = A + row * cols * N;
+        uint32_t S[2 * N];
 #pragma unroll
-        for (int l = 0; l < N; l++) acc[l] = 0;
-        for (size_t j = threadIdx.x; j < cols; j += kBlock) {
-            uint32_t a[N], b[N], pr[N], s[N];
-            load_elem<N>(a, Arow, j);
-            load_elem<N>(b, x, j);
-            mont_mul<N>(pr, a, b, P);
-            mod_add<N>(s, acc, pr, P);
+        for (int l = 0; l < 2 * N; l++) S[l] = 0;
+        size_t j = threadIdx.x;
+        if constexpr (T > 1) {
+            for (; j + (size_t)(T - 1) * kBlock < cols; j += (size_t)T * kBlock) {
+                uint32_t a[T][N], b[T][N], prod[2 * N];
 #pragma unroll
-            for (int l = 0; l < N; l++) acc[l] = s[l];
+                for (int t = 0; t < T; t++) {
+                    load_elem<N>(a[t], Arow, j + (size_t)t * kBlock);
+                    load_elem<N>(b[t], x, j + (size_t)t * kBlock);
+                }
+                mul_wide_sum<N, T>(prod, a, b);
+                wide_acc_add<N>(S, prod, P);
+            }
         }
+        for (; j < cols; j += kBlock) {
+            uint32_t a[1][N], b[1][N], prod[2 * N];
+            load_elem<N>(a[0], Arow, j);
+            load_elem<N>(b[0], x, j);
+            mul_wide_sum<N, 1>(prod, a, b);
+            wide_acc_add<N>(S, prod, P);
+        }
+        uint32_t acc[N];
+        mont_redc_wide<N>(acc, S, P);
         wave_reduce_add<N>(acc, P);
         const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
         if (lane == 0) {
@@ -333,15 +352,15 @@ __global__ __launch_bounds__(kBlock) void k_matvec(const uint32_t* __restrict__ 
         }
         __syncthreads();
         if (threadIdx.x == 0) {
-            uint32_t tot[N], o[N], r[N];
+            uint32_t tot[N], o[N], t[N];
 #pragma unroll
             for (int l = 0; l < N; l++) tot[l] = part[0][l];
             for (int w = 1; w < kBlock / 64; w++) {
 #pragma unroll
                 for (int l = 0; l < N; l++) o[l] = part[w][l];
-                mod_add<N>(r, tot, o, P);
+                mod_add<N>(t, tot, o, P);
 #pragma unroll
-                for (int l = 0; l < N; l++) tot[l] = r[l];
+                for (int l = 0; l < N; l++) tot[l] = t[l];
             }
             store_elem<N>(y, row, tot);
         }
