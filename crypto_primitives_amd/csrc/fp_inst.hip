@@ -104,13 +104,16 @@ void Launch<N>::matvec(const fpgpu_ctx* ctx, const void* A, size_t rows, size_t 
                        hipStream_t s) {
     // Terms per product-scanning pass: T products may be summed before the wide add only
     // if T*p <= R, i.e. the modulus leaves log2(T) zero bits at the top of its container.
-    // FPGPU_MATVEC_T overrides (downwards only) for A/B measurements.
+    // Measured on MI355X (2^15 x 2^15, BN254): T = 1 (66 VGPRs, 7 waves/SIMD) 6.96 ms,
+    // T = 2 7.3 ms, T = 4 (125 VGPRs, 4 waves) 7.9 ms -- occupancy beats the saved column
+    // shifts, so T = 1 is the default; FPGPU_MATVEC_T selects 2 or 4 for experiments.
     static const int t_env = [] { const char* e = getenv("FPGPU_MATVEC_T"); return e ? atoi(e) : 0; }();
     int lz = __builtin_clzll(ctx->modulus[ctx->n64 - 1] | 1);
     if (ctx->modulus[ctx->n64 - 1] == 0) lz = 64;
-    int T = lz >= 2 ? 4 : (lz >= 1 ? 2 : 1);
-    if (N > 8 && T > 2) T = 2;  // register budget (T = 4 at N = 12 needs 182 VGPRs)
-    if (t_env > 0 && t_env < T) T = t_env;
+    int Tmax = lz >= 2 ? 4 : (lz >= 1 ? 2 : 1);
+    if (N > 8 && Tmax > 2) Tmax = 2;  // register budget (T = 4 at N = 12 needs 182 VGPRs)
+    int T = 1;
+    if (t_env > 1) T = t_env < Tmax ? t_env : Tmax;
     int grid = (int)(rows < 65536 ? rows : 65536);
     const uint32_t* Ap = (const uint32_t*)A;
     const uint32_t* xp = (const uint32_t*)x;

@@ -84,89 +84,111 @@ __global__ __launch_bounds__(kBlock) void k_fill_random(uint32_t* __restrict__ o
     }
 }
 
-// ---- binary extended GCD inversion, one element per lane (vartime) -------------
-// Plain (non-Montgomery) inverse of a mod p for odd p; returns false when
-// gcd(a, p) != 1 (the reference's invert_odd_mod_vartime -> None).  Used only at
-// the top level of batch inversion and on its composite-modulus fallback path.
+// ---- modular inversion of single elements (top level of batch inversion) -----------
+// Kaliski's "almost Montgomery inverse", phase 1, written branch-free so that the 64
+// lanes of a wave run ONE instruction stream (the textbook 4-way branching binary GCD
+// serialises every taken branch per iteration: 1.4 ms for one 384-bit inversion on
+// MI355X; this form: ~0.15 ms).  For odd p and 0 < a < p it returns r = a^-1 * 2^k mod p
+// with len(p) <= k <= 2 len(p), and reports gcd(a, p) == 1.  r and s stay <= 2p, so they
+// carry one extra limb.
 template <int N>
-__device__ __forceinline__ void shr1(uint32_t (&a)[N], uint32_t top) {
+__device__ __forceinline__ bool almost_inverse(uint32_t (&r_out)[N], uint32_t& k_out, const uint32_t (&a)[N],
+                                               const FpParams<N>& P) {
+    uint32_t u[N], v[N], r[N + 1], s[N + 1];
 #pragma unroll
-    for (int i = 0; i < N - 1; i++) a[i] = (a[i] >> 1) | (a[i + 1] << 31);
-    a[N - 1] = (a[N - 1] >> 1) | (top << 31);
-}
-template <int N>
-__device__ __forceinline__ bool ge_limbs(const uint32_t (&a)[N], const uint32_t (&b)[N]) {
-    uint32_t d[N];
-    return sub_limbs<N>(d, a, b) == 0;
-}
-template <int N>
-__device__ __forceinline__ bool is_one(const uint32_t (&a)[N]) {
-    uint32_t z = a[0] ^ 1u;
+    for (int i = 0; i < N; i++) { u[i] = P.m[i]; v[i] = a[i]; r[i] = 0; s[i] = 0; }
+    r[N] = 0; s[N] = 0; s[0] = 1;
+    uint32_t k = 0;
+    for (int iter = 0; iter < 64 * N + 2; iter++) {
+        const bool active = !is_zero<N>(v);
+        if (!__any(active)) break;
+        uint32_t d1[N], d2[N], rs[N + 1];
+        const uint32_t b1 = sub_limbs<N>(d1, u, v);   // u - v, borrow <=> u < v
+        sub_limbs<N>(d2, v, u);                        // v - u
+        add_limbs<N + 1>(rs, r, s);
+        const uint32_t act = active ? ~0u : 0u;
+        const uint32_t ue = 0u - (~u[0] & 1u), ve = 0u - (~v[0] & 1u);       // all-ones if even
+        const uint32_t gt = (b1 == 0 && !is_zero<N>(d1)) ? ~0u : 0u;          // u > v
+        const uint32_t cA = act & ue;
+        const uint32_t cB = act & ~ue & ve;
+        const uint32_t cC = act & ~ue & ~ve & gt;
+        const uint32_t cD = act & ~ue & ~ve & ~gt;
+        const uint32_t hu = cA | cC, hv = cB | cD;     // halve u / halve v (and double s / r)
+        // masks select with v_bfi/v_cndmask: one instruction stream for all 64 lanes
 #pragma unroll
-    for (int i = 1; i < N; i++) z |= a[i];
-    return z == 0;
-}
-template <int N>
-__device__ __forceinline__ bool inv_gcd(uint32_t (&r)[N], const uint32_t (&a_in)[N], const FpParams<N>& P) {
-    uint32_t u[N], v[N], x1[N], x2[N], m[N], t[N];
+        for (int i = 0; i < N; i++) {
+            u[i] = (d1[i] & cC) | (u[i] & ~cC);
+            v[i] = (d2[i] & cD) | (v[i] & ~cD);
+        }
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            const uint32_t un = i + 1 < N ? u[i + 1] : 0u, vn = i + 1 < N ? v[i + 1] : 0u;
+            const uint32_t uh = (u[i] >> 1) | (un << 31), vh = (v[i] >> 1) | (vn << 31);
+            u[i] = (uh & hu) | (u[i] & ~hu);
+            v[i] = (vh & hv) | (v[i] & ~hv);
+        }
+        // r' = (B or D) ? 2r : (C ? r+s : r);   s' = (A or C) ? 2s : (D ? r+s : s)
+        uint32_t rp = 0, sp = 0;
+#pragma unroll
+        for (int i = 0; i <= N; i++) {
+            const uint32_t r2x = (r[i] << 1) | rp, s2x = (s[i] << 1) | sp;
+            rp = r[i] >> 31; sp = s[i] >> 31;
+            const uint32_t rc = (rs[i] & cC) | (r[i] & ~cC);
+            const uint32_t sc = (rs[i] & cD) | (s[i] & ~cD);
+            r[i] = (r2x & hv) | (rc & ~hv);
+            s[i] = (s2x & hu) | (sc & ~hu);
+        }
+        k += act & 1u;
+    }
+    // gcd(a, p) is what is left in u
+    uint32_t nz = u[0] ^ 1u;
+#pragma unroll
+    for (int i = 1; i < N; i++) nz |= u[i];
+    const bool ok = nz == 0;
+    // r in [0, 2p]: bring below p, then negate: a^-1 2^k = p - r
+    uint32_t m[N], t[N], rl[N];
     set_limbs<N>(m, P.m);
 #pragma unroll
-    for (int i = 0; i < N; i++) { u[i] = a_in[i]; v[i] = m[i]; x1[i] = 0; x2[i] = 0; }
-    x1[0] = 1;
-    // reduce u below p (inputs are expected canonical; stay total)
-    for (int guard = 0; guard < 4 && ge_limbs<N>(u, m); guard++) sub_limbs<N>(u, u, m);
-    if (is_zero<N>(u)) return false;
-    if (is_one<N>(m)) return false;
-    // every subtraction is followed by a halving and u, v hold <= 32N bits each, so
-    // at most 2 * 2 * 32N + 2 single-action iterations are needed
-    for (int iter = 0; iter < 128 * N + 16; iter++) {
-        if (is_one<N>(u) || is_one<N>(v)) break;
-        if (is_zero<N>(u) || is_zero<N>(v)) return false;
-        if ((u[0] & 1u) == 0) {
-            shr1<N>(u, 0);
-            uint32_t c = 0;
-            if (x1[0] & 1u) c = add_limbs<N>(x1, x1, m);
-            shr1<N>(x1, c);
-        } else if ((v[0] & 1u) == 0) {
-            shr1<N>(v, 0);
-            uint32_t c = 0;
-            if (x2[0] & 1u) c = add_limbs<N>(x2, x2, m);
-            shr1<N>(x2, c);
-        } else if (ge_limbs<N>(u, v)) {
-            sub_limbs<N>(u, u, v);
-            if (sub_limbs<N>(t, x1, x2)) add_limbs<N>(t, t, m);
+    for (int i = 0; i < N; i++) rl[i] = r[i];
+    uint32_t top = r[N];
+#pragma unroll 1
+    for (int pass = 0; pass < 2; pass++) {
+        const uint32_t bo = sub_limbs<N>(t, rl, m);
+        const uint32_t take = ((top != 0) || (bo == 0)) ? ~0u : 0u;
 #pragma unroll
-            for (int i = 0; i < N; i++) x1[i] = t[i];
-        } else {
-            sub_limbs<N>(v, v, u);
-            if (sub_limbs<N>(t, x2, x1)) add_limbs<N>(t, t, m);
-#pragma unroll
-            for (int i = 0; i < N; i++) x2[i] = t[i];
-        }
+        for (int i = 0; i < N; i++) rl[i] = (t[i] & take) | (rl[i] & ~take);
+        top = take ? (top - bo) : top;
     }
-    if (is_one<N>(u)) {
+    sub_limbs<N>(t, m, rl);                            // p - r  (r == 0 cannot happen when ok)
 #pragma unroll
-        for (int i = 0; i < N; i++) r[i] = x1[i];
-        return true;
-    }
-    if (is_one<N>(v)) {
-#pragma unroll
-        for (int i = 0; i < N; i++) r[i] = x2[i];
-        return true;
-    }
-    return false;
+    for (int i = 0; i < N; i++) r_out[i] = t[i];
+    k_out = k;
+    return ok;
 }
 
-// Montgomery-form inverse exactly as MontyField::inv (crypto_bigint_monty.rs:223-237):
-// invert the representative, then two Montgomery multiplications by R^2.
+// Montgomery-form inverse with the reference's meaning (MontyField::inv,
+// crypto_bigint_monty.rs:223-237): x holds X = xR; the result is X^-1 * R^2 = x^-1 R.
+// From r = X^-1 2^k: two multiplications by R^2 give r 2^(2m) (m = 32N), and two
+// multiplications by single-bit operands 2^j1, 2^j2 with j1 + j2 = 2m - k divide by 2^k.
 template <int N>
-__device__ __forceinline__ bool mont_inv_gcd(uint32_t (&r)[N], const uint32_t (&x)[N], const FpParams<N>& P) {
-    uint32_t inv[N], r2[N], t[N];
-    if (!inv_gcd<N>(inv, x, P)) return false;
-    set_limbs<N>(r2, P.r2);
-    mont_mul<N>(t, inv, r2, P);
-    mont_mul<N>(r, t, r2, P);
-    return true;
+__device__ __forceinline__ bool mont_inv_gcd(uint32_t (&out)[N], const uint32_t (&x)[N], const FpParams<N>& P) {
+    uint32_t r[N], t[N], c[N];
+    uint32_t k = 0;
+    const bool ok = almost_inverse<N>(r, k, x, P);
+    set_limbs<N>(c, P.r2);
+    mont_mul<N>(t, r, c, P);
+    mont_mul<N>(r, t, c, P);
+    const uint32_t m = 32u * N;
+    const uint32_t e = 2u * m - (ok ? k : m);          // k <= 2 len(p) <= 2m; keep shifts sane when !ok
+    const uint32_t j1 = e < m - 1 ? e : m - 1;
+    const uint32_t j2 = e - j1;                         // <= m - 1 because k >= 2 for every p >= 3
+#pragma unroll
+    for (int i = 0; i < N; i++) c[i] = ((uint32_t)i == (j1 >> 5)) ? (1u << (j1 & 31)) : 0u;
+    mont_mul<N>(t, r, c, P);
+#pragma unroll
+    for (int i = 0; i < N; i++) c[i] = ((uint32_t)i == (j2 >> 5)) ? (1u << (j2 & 31)) : 0u;
+    mont_mul<N>(out, t, c, P);
+    return ok;
 }
 
 // ---- batch inversion: Montgomery's trick over interleaved chains -----------------

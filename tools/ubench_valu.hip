@@ -48,6 +48,20 @@ __global__ __launch_bounds__(256) void k_bench(uint32_t* out, uint32_t seed, uns
           "v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
           : "+v"(c0), "+v"(d0) : "v"(a), "v"(b) : "vcc");)
       // counts as 8 mads + 8 addc per R4 -> 16 instr, 8 "steps"
+    } else if constexpr (KIND == 14) {  // mad ; s_nop 1 ; addc  (hazard-padded product-scanning step)
+      R4(asm volatile(
+          "v_mad_u64_u32 %0, vcc, %2, %3, %0\n\ts_nop 1\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+          "v_mad_u64_u32 %0, vcc, %2, %3, %0\n\ts_nop 1\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+          : "+v"(c0), "+v"(d0) : "v"(a), "v"(b) : "vcc");)
+    } else if constexpr (KIND == 15) {  // software-pipelined carries: 3 rotating SGPR pairs, no nops
+      unsigned long long s0, s1, s2;
+      R4(asm volatile(
+          "v_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_mad_u64_u32 %0, %3, %5, %6, %0\n\t"
+          "v_mad_u64_u32 %0, %4, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\t"
+          "v_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %3, 0, %1, %3\n\t"
+          "v_addc_co_u32 %1, %4, 0, %1, %4\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\t"
+          : "+v"(c0), "+v"(d0), "=&s"(s0), "=&s"(s1), "=&s"(s2) : "v"(a), "v"(b));)
+      // 8 instr per R4 unit x2 ... counts as 16 instr per iteration? (4 mad + 4 addc) x 4 = 32
     } else if constexpr (KIND == 3) {  // v_mul_lo_u32 independent
       R4(asm volatile(
           "v_mul_lo_u32 %0, %0, %4\n\tv_mul_lo_u32 %1, %1, %4\n\tv_mul_lo_u32 %2, %2, %4\n\tv_mul_lo_u32 %3, %3, %4\n\t"
@@ -144,6 +158,8 @@ int main() {
     run<0>("mad_u64_u32_indep8", bpc, ncu, dout, dcyc);
     run<1>("mad_u64_u32_dep", bpc, ncu, dout, dcyc);
     run<2>("mad+addc_dep(16inst=8steps)", bpc, ncu, dout, dcyc);
+    run<14>("mad+nop1+addc_dep(16inst+8nop)", bpc, ncu, dout, dcyc);
+    run<15>("mad/addc_swpipelined_sgpr(32inst!)", bpc, ncu, dout, dcyc);
     run<11>("mad_u64_u32_sgpr_src", bpc, ncu, dout, dcyc);
     run<13>("mad_u64_u32_addend0", bpc, ncu, dout, dcyc);
     run<3>("mul_lo_u32", bpc, ncu, dout, dcyc);
