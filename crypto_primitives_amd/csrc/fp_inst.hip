@@ -22,8 +22,7 @@ static FpParams<N> make_params(const fpgpu_ctx* c) {
         P.one[2 * i + 1] = (uint32_t)(c->one[i] >> 32);
     }
     P.n0inv = (uint32_t)c->mod_neg_inv;
-    P.top_mask = (uint32_t)c->top_mask;
-    P.top_mask_hi = (uint32_t)(c->top_mask >> 32);
+    P.bitlen = c->bitlen;
     return P;
 }
 
@@ -107,7 +106,8 @@ void Launch<N>::matvec(const fpgpu_ctx* ctx, const void* A, size_t rows, size_t 
     // Measured on MI355X (2^15 x 2^15, BN254): T = 1 (66 VGPRs, 7 waves/SIMD) 6.96 ms,
     // T = 2 7.3 ms, T = 4 (125 VGPRs, 4 waves) 7.9 ms -- occupancy beats the saved column
     // shifts, so T = 1 is the default; FPGPU_MATVEC_T selects 2 or 4 for experiments.
-    static const int t_env = [] { const char* e = getenv("FPGPU_MATVEC_T"); return e ? atoi(e) : 0; }();
+    const char* t_str = getenv("FPGPU_MATVEC_T");  // read per call so tests can cover every T
+    const int t_env = t_str ? atoi(t_str) : 0;
     int lz = __builtin_clzll(ctx->modulus[ctx->n64 - 1] | 1);
     if (ctx->modulus[ctx->n64 - 1] == 0) lz = 64;
     int Tmax = lz >= 2 ? 4 : (lz >= 1 ? 2 : 1);

@@ -75,8 +75,11 @@ __global__ __launch_bounds__(kBlock) void k_fill_random(uint32_t* __restrict__ o
             x[2 * l] = (uint32_t)w;
             x[2 * l + 1] = (uint32_t)(w >> 32);
         }
-        x[N - 2] &= P.top_mask;
-        x[N - 1] &= P.top_mask_hi;
+#pragma unroll
+        for (int l = 0; l < N; l++) {  // keep bitlen(p) bits: candidate < 2^bitlen <= 2p
+            const int nb = (int)P.bitlen - 32 * l;
+            x[l] &= nb >= 32 ? ~0u : (nb <= 0 ? 0u : ((1u << nb) - 1u));
+        }
         uint32_t bo = sub_limbs_s<N>(d, x, P.m);
 #pragma unroll
         for (int l = 0; l < N; l++) x[l] = bo ? x[l] : d[l];

@@ -14,7 +14,7 @@ struct fpgpu_ctx {
     uint64_t one[FPGPU_MAX_N64];
     uint64_t r2[FPGPU_MAX_N64];
     uint64_t mod_neg_inv;
-    uint64_t top_mask;  // significant bits of the top word of the modulus
+    uint32_t bitlen;    // bit length of the modulus
 };
 
 namespace fpgpu {

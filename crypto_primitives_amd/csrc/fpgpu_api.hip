@@ -208,14 +208,10 @@ int fpgpu_ctx_create(const uint64_t* modulus_le, uint32_t n64, fpgpu_ctx** out) 
     std::memcpy(c->one, t, sizeof t);
     for (uint32_t i = 0; i < 64 * n64; i++) double_mod(t, c->modulus, n64);
     std::memcpy(c->r2, t, sizeof t);
-    // bit mask of the modulus' top word (for the synthetic generator)
-    uint64_t top = c->modulus[n64 - 1];
-    uint64_t mask = ~(uint64_t)0;
-    if (top != 0) {
-        int lz = __builtin_clzll(top);
-        mask = lz ? (((uint64_t)1 << (64 - lz)) - 1) : ~(uint64_t)0;
-    }
-    c->top_mask = mask;
+    // bit length of the modulus (for the synthetic generator)
+    c->bitlen = 0;
+    for (int i = (int)n64 - 1; i >= 0; i--)
+        if (c->modulus[i]) { c->bitlen = 64u * i + 64u - (uint32_t)__builtin_clzll(c->modulus[i]); break; }
     *out = c;
     return FPGPU_OK;
 }

@@ -114,7 +114,7 @@ int fpgpu_matmul_dev(const fpgpu_ctx *ctx, const void *A, const void *B, void *C
 
 /* ---- synthetic inputs -------------------------------
  * Fills `out` with n uniform elements in [0, p): word l of element i is
- * splitmix64(seed ^ (i*n64 + l)), top word masked to bitlen(p), minus p once if >= p.
+ * splitmix64(seed ^ (i*n64 + l)), the value masked to bitlen(p) bits, minus p once if >= p.
  * Identical to the host generator in bench.py / tests. */
 int fpgpu_fill_random_dev(const fpgpu_ctx *ctx, void *out, size_t n, uint64_t seed, void *stream);
 

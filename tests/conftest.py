@@ -56,17 +56,13 @@ def splitmix64(z):
 
 def synth_elements(p, n64, n, seed):
     """Host twin of fpgpu_fill_random_dev (SURVEY.md section 8d generator)."""
-    bl = p.bit_length()
-    top_bits = bl - 64 * (n64 - 1)
-    mask = (1 << top_bits) - 1 if top_bits < 64 else 0xFFFFFFFFFFFFFFFF
+    mask = (1 << p.bit_length()) - 1
     out = []
     for i in range(n):
         v = 0
         for l in range(n64):
-            w = splitmix64(seed ^ (i * n64 + l))
-            if l == n64 - 1:
-                w &= mask
-            v |= w << (64 * l)
+            v |= splitmix64(seed ^ (i * n64 + l)) << (64 * l)
+        v &= mask
         if v >= p:
             v -= p
         out.append(v)

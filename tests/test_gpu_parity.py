@@ -229,6 +229,22 @@ def test_matvec_vs_oracle(cpa, shape):
         assert np.array_equal(f.matvec(A, rows, cols, x), o.matvec(A, rows, cols, x, threads=0))
 
 
+@pytest.mark.parametrize("T", ["2", "4"])
+def test_matvec_multi_term_passes(cpa, T, monkeypatch):
+    """The T-products-per-pass mat-vec variants (selected with FPGPU_MATVEC_T; T = 1 is the
+    default) must give the same canonical residues; moduli without headroom fall back to
+    T = 1 inside the library."""
+    monkeypatch.setenv("FPGPU_MATVEC_T", T)
+    for name in ("bn254_fr", "bls12_381_fq", "bench_120bit", "secp256k1_p", "goldilocks"):
+        g = load_golden(name)
+        p, n64 = h2i(g["modulus"]), g["n64"]
+        f, o = field_of(cpa, g), oracle_of(g)
+        for rows, cols in ((3, 2100), (5, 1024), (2, 777)):
+            A = ints_to_array(synth_elements(p, n64, rows * cols, 53), n64)
+            x = ints_to_array(synth_elements(p, n64, cols, 54), n64)
+            assert np.array_equal(f.matvec(A, rows, cols, x), o.matvec(A, rows, cols, x, threads=0))
+
+
 @pytest.mark.parametrize("shape", [(1, 1, 1), (16, 16, 16), (33, 70, 17), (100, 129, 65)])
 def test_matmul_vs_oracle(cpa, shape):
     m, k, n = shape
