@@ -137,6 +137,16 @@ def main():
                 verified = f"unchecked: {e}"
         unit = {"mul": "Gmul/s", "sqr": "Gsqr/s", "add": "Gadd/s", "sub": "Gsub/s"}[args.workload]
         achieved = bytes_per * n / kern / 1e9
+        # HBM bytes per launch from the PMC passes kept under profiles/ (collected with
+        # rocprofv3 --pmc on this same command; bench.py cannot run the profiler on itself)
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic_%s.json" % args.workload)) as fh:
+                pmc = json.load(fh)
+            if pmc.get("elements") == n:
+                traffic = pmc["traffic_bytes_per_launch"]
+        except (OSError, ValueError, KeyError):
+            pass
         result = {
             "metric": "256-bit Montgomery %s (BN254 Fr, HBM-resident batch)" % unit,
             "value": value, "unit": unit,
@@ -146,7 +156,9 @@ def main():
                                    "(BASELINE.json configs[1])" % (args.workload, args.log2n),
                        "elements_per_gpu": n, "limbs64": 4, "parallelism": "shard%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "traffic_unit": "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/pmc_traffic_*.json)",
+                         "algorithmic_bytes_per_launch": bytes_per * n,
                          "kernel": "k_elementwise<8,%s>" % args.workload, "bytes_per_element": bytes_per,
                          "kernel_ms": kern * 1e3},
             "verified_vs_oracle": verified,
