@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--log2n", type=int, default=28, help="elements per GPU = 2^log2n")
-    ap.add_argument("--workload", default="mul", choices=["mul", "sqr", "add", "sub", "matvec", "batch_inv"])
+    ap.add_argument("--workload", default="mul", choices=["mul", "sqr", "add", "sub", "matvec", "batch_inv", "matmul"])
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary measurements")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--matvec-log2", type=int, default=15, help="mat-vec is 2^k x 2^k")
@@ -167,6 +167,8 @@ def main():
         result = bench_matvec(args, f, world, rank, distributed, time_steps, primary=True)
     elif args.workload == "batch_inv":
         result = bench_batch_inv(args, world, rank, time_steps, primary=True)
+    elif args.workload == "matmul":
+        result = bench_matmul(args, world, rank, distributed, time_steps, primary=True)
 
     # ---------------- secondary measurements ------------------------------------------
     if not args.no_extra:
@@ -187,6 +189,8 @@ def main():
                               "valu_frac_vs_136_mads": gmul * 136 / 1e3 / VALU_MAD_PEAK_TOPS}
         if args.workload != "batch_inv":
             extra["batch_inv_bls12_381"] = bench_batch_inv(args, world, rank, time_steps, primary=False)
+        if args.workload != "matmul":
+            extra["matmul_goldilocks"] = bench_matmul(args, world, rank, distributed, time_steps, primary=False)
         if args.workload != "matvec":
             extra["matvec_bn254"] = bench_matvec(args, f, world, rank, distributed, time_steps, primary=False)
 
@@ -242,6 +246,46 @@ def bench_batch_inv(args, world, rank, time_steps, primary):
                "roofline": {"bound": "hbm", "achieved": 96 * n / kern / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                             "frac": 96 * n / kern / 1e9 / HBM_PEAK_GBPS, "traffic": None},
                "verified_vs_oracle": ok}
+    return res
+
+
+def bench_matmul(args, world, rank, distributed, time_steps, primary):
+    """BASELINE.json configs[4]: MontyField 64-bit single-limb prime (Goldilocks) 8192^2 mat-mul.
+    A and C are row-sharded across ranks, B is replicated (strong scaling); C slices are
+    all-gathered when N > 1."""
+    import torch
+    import torch.distributed as dist
+    import crypto_primitives_amd as cpa
+    g = cpa.MontyField(cpa.GOLDILOCKS, 1)
+    dim = 8192
+    rows = dim // world
+    A = g.random_dev(rows * dim, 0x60 ^ (13 + 1000 * rank))
+    B = g.random_dev(dim * dim, 0x61)
+    C_local = g.alloc(rows * dim)
+    C = g.alloc(dim * dim) if distributed else C_local
+
+    def step():
+        g.matmul_dev(A, B, C_local, rows, dim, dim)
+        if distributed:
+            dist.all_gather_into_tensor(C, C_local)
+
+    steps = max(2, min(args.steps, 5)) if not primary else args.steps
+    wall, kern = time_steps(step, steps, 1)
+    terms = dim ** 3
+    res = {"Gterms_per_s": terms * steps / wall / 1e9, "ms_per_matmul": wall / steps * 1e3, "dim": dim,
+           "valu_lane_instr_Tops_per_gpu": 8.0 * rows * dim * dim / kern / 1e12,
+           "valu_issue_peak_Tops": 36.5,
+           "algorithmic_mad_Tops_per_gpu(10 per term)": 10.0 * rows * dim * dim / kern / 1e12}
+    if primary:
+        res = {"metric": "64-bit Fp mat-mul Gterms/s (Goldilocks, 8192^2)", "value": res["Gterms_per_s"],
+               "unit": "Gterms/s", "per_gpu": res["Gterms_per_s"] / world, "ms_per_step": res["ms_per_matmul"],
+               "config": {"workload": "Goldilocks 64-bit 8192 x 8192 x 8192 mat-mul (BASELINE.json configs[4])",
+                          "parallelism": "rowshard%d" % world},
+               "roofline": {"bound": "valu", "achieved": res["valu_lane_instr_Tops_per_gpu"], "peak": 39.3,
+                            "unit": "T lane-instr/s (8 VALU instr per term: 4 v_mad_u64_u32 + 4 v_addc_co_u32)",
+                            "frac": res["valu_lane_instr_Tops_per_gpu"] / 39.3, "traffic": None,
+                            "kernel": "k_matmul_1limb"},
+               "verified_vs_oracle": None}
     return res
 
 

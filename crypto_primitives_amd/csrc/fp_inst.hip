@@ -129,6 +129,17 @@ void Launch<N>::matvec(const fpgpu_ctx* ctx, const void* A, size_t rows, size_t 
 template <int N>
 void Launch<N>::matmul(const fpgpu_ctx* ctx, const void* A, const void* B, void* C, size_t m, size_t k, size_t n,
                        hipStream_t s) {
+    if constexpr (N == 2) {
+        // single-limb fast path (register-tiled, lazily reduced); FPGPU_MATMUL_GENERIC=1 forces
+        // the generic kernel for A/B checks
+        const char* g = getenv("FPGPU_MATMUL_GENERIC");
+        if (!(g && atoi(g))) {
+            size_t gx = (n + kMM1_BN - 1) / kMM1_BN, gy = (m + kMM1_BM - 1) / kMM1_BM;
+            hipLaunchKernelGGL((k_matmul_1limb<N>), dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, s, (const uint2*)A,
+                               (const uint2*)B, (uint2*)C, m, k, n, make_params<N>(ctx));
+            return;
+        }
+    }
     size_t gx = (n + kMMTile - 1) / kMMTile, gy = (m + kMMTile - 1) / kMMTile;
     hipLaunchKernelGGL((k_matmul<N>), dim3((unsigned)gx, (unsigned)gy), dim3(kMMTile * kMMTile), 0, s,
                        (const uint32_t*)A, (const uint32_t*)B, (uint32_t*)C, m, k, n, make_params<N>(ctx));

@@ -442,4 +442,127 @@ __global__ __launch_bounds__(kMMTile* kMMTile) void k_matmul(const uint32_t* __r
     if (row < m && col < n) store_elem<N>(Cm, row * n + col, acc);
 }
 
+
+// ---- single-limb (n64 = 1, N = 2) mat-mul: register-tiled, lazily reduced -------------
+// BASELINE.json configs[4]: MontyField 64-bit prime (Goldilocks-size) 8192^2 mat-mul.
+// Workgroup = 256 lanes computing a 64 x 32 tile of C; lane (ty, tx) owns 4 x 2 outputs.
+// K is walked in 32-deep steps staged through LDS (A transposed to [k][row] so a lane's
+// four rows are one 32-byte read; B as is), with the next step's global loads held in
+// registers while the current step computes.  Every term a*b (64 x 64 -> 128 bits) is four
+// v_mad_u64_u32 into three per-output 96-bit accumulators (weights 2^0, 2^32, 2^64) plus
+// four carry adds: 8 VALU instructions per term, no reduction, no shifts.  One asm block
+// per term keeps each carry two instructions away from its consumer (see fp_device.cuh).
+// The 160-bit sums are reduced once per output: with S = s0 + s1 R + s2 R^2,
+//   S R^-1 mod p = mont_mul(s0, 1) + mont_mul(s1, R mod p) + mont_mul(s2, R^2 mod p),
+// valid for every odd p < 2^64 and any K < 2^32; canonical, hence bit-identical to the
+// reference's fold of mul and add.
+struct Acc3 {
+    uint64_t p, q, r;     // low 64 bits of the three partial-product sums
+    uint32_t ph, qh, rh;  // their carry counts
+};
+__device__ __forceinline__ void mac_1limb(Acc3& c, uint32_t a0, uint32_t a1, uint32_t b0, uint32_t b1) {
+    uint64_t c0, c1, c2;
+    asm("v_mad_u64_u32 %0, %6, %9, %11, %0\n\t"
+        "v_mad_u64_u32 %1, %7, %9, %12, %1\n\t"
+        "v_mad_u64_u32 %2, %8, %10, %12, %2\n\t"
+        "v_addc_co_u32 %3, %6, 0, %3, %6\n\t"
+        "v_mad_u64_u32 %1, %6, %10, %11, %1\n\t"
+        "v_addc_co_u32 %4, %7, 0, %4, %7\n\t"
+        "v_addc_co_u32 %5, %8, 0, %5, %8\n\t"
+        "v_addc_co_u32 %4, %6, 0, %4, %6"
+        : "+v"(c.p), "+v"(c.q), "+v"(c.r), "+v"(c.ph), "+v"(c.qh), "+v"(c.rh), "=&s"(c0), "=&s"(c1), "=&s"(c2)
+        : "v"(a0), "v"(a1), "v"(b0), "v"(b1));
+}
+
+constexpr int kMM1_BM = 64, kMM1_BN = 32, kMM1_BK = 32, kMM1_TM = 4, kMM1_TN = 2;
+
+template <int N>  // N == 2 only; a template so that each limb-count translation unit may include it
+__global__ __launch_bounds__(256) void k_matmul_1limb(const uint2* __restrict__ A, const uint2* __restrict__ B,
+                                                      uint2* __restrict__ Cm, size_t m, size_t k, size_t n,
+                                                      const FpParams<N> P) {
+    static_assert(N == 2, "single-limb kernel");
+    __shared__ uint2 sA[kMM1_BK][kMM1_BM];  // [k][row]
+    __shared__ uint2 sB[kMM1_BK][kMM1_BN];  // [k][col]
+    const int tid = threadIdx.x;
+    const int tx = tid & 15, ty = tid >> 4;            // 16 x 16 lanes
+    const size_t row0 = (size_t)blockIdx.y * kMM1_BM, col0 = (size_t)blockIdx.x * kMM1_BN;
+    // staging roles: A tile 64 rows x 32 k = 2048 elements, 8 per lane (row = tid/4, k = (tid%4)*8 ..+7)
+    const int a_r = tid >> 2, a_k = (tid & 3) * 8;
+    // B tile 32 k x 32 cols = 1024 elements, 4 per lane (k = tid/8, col = (tid%8)*4 ..+3)
+    const int b_k = tid >> 3, b_c = (tid & 7) * 4;
+    uint2 ra[8], rb[4];
+    auto fetch = [&](size_t k0) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            size_t r = row0 + a_r, kk = k0 + a_k + i;
+            ra[i] = (r < m && kk < k) ? A[r * k + kk] : make_uint2(0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            size_t kk = k0 + b_k, c = col0 + b_c + i;
+            rb[i] = (kk < k && c < n) ? B[kk * n + c] : make_uint2(0, 0);
+        }
+    };
+    Acc3 acc[kMM1_TM][kMM1_TN];
+#pragma unroll
+    for (int i = 0; i < kMM1_TM; i++)
+#pragma unroll
+        for (int j = 0; j < kMM1_TN; j++) acc[i][j] = Acc3{0, 0, 0, 0, 0, 0};
+    fetch(0);
+    for (size_t k0 = 0; k0 < k; k0 += kMM1_BK) {
+        __syncthreads();  // previous step's reads are done
+#pragma unroll
+        for (int i = 0; i < 8; i++) sA[a_k + i][a_r] = ra[i];
+#pragma unroll
+        for (int i = 0; i < 4; i++) sB[b_k][b_c + i] = rb[i];
+        __syncthreads();
+        if (k0 + kMM1_BK < k) fetch(k0 + kMM1_BK);  // in flight while this step computes
+#pragma unroll 4
+        for (int kk = 0; kk < kMM1_BK; kk++) {
+            uint2 av[kMM1_TM], bv[kMM1_TN];
+#pragma unroll
+            for (int i = 0; i < kMM1_TM; i++) av[i] = sA[kk][ty * kMM1_TM + i];
+#pragma unroll
+            for (int j = 0; j < kMM1_TN; j++) bv[j] = sB[kk][tx * kMM1_TN + j];
+#pragma unroll
+            for (int i = 0; i < kMM1_TM; i++)
+#pragma unroll
+                for (int j = 0; j < kMM1_TN; j++) mac_1limb(acc[i][j], av[i].x, av[i].y, bv[j].x, bv[j].y);
+        }
+    }
+    // reduce and store
+    uint32_t onep[2] = {1u, 0u}, oneR[2], r2[2];
+    set_limbs<2>(oneR, P.one);
+    set_limbs<2>(r2, P.r2);
+#pragma unroll
+    for (int i = 0; i < kMM1_TM; i++)
+#pragma unroll
+        for (int j = 0; j < kMM1_TN; j++) {
+            const size_t r = row0 + ty * kMM1_TM + i, c = col0 + tx * kMM1_TN + j;
+            if (r >= m || c >= n) continue;
+            const Acc3& a = acc[i][j];
+            // S = P + Q 2^32 + R 2^64 as six 32-bit limbs
+            uint32_t S[6];
+            unsigned cy = 0;
+            S[0] = (uint32_t)a.p;
+            S[1] = __builtin_addc((uint32_t)(a.p >> 32), (uint32_t)a.q, cy, &cy);
+            S[2] = __builtin_addc(a.ph, (uint32_t)(a.q >> 32), cy, &cy);
+            S[3] = __builtin_addc(a.qh, 0u, cy, &cy);
+            S[4] = cy;
+            cy = 0;
+            S[2] = __builtin_addc(S[2], (uint32_t)a.r, cy, &cy);
+            S[3] = __builtin_addc(S[3], (uint32_t)(a.r >> 32), cy, &cy);
+            S[4] = __builtin_addc(S[4], a.rh, cy, &cy);
+            S[5] = cy;
+            uint32_t s0[2] = {S[0], S[1]}, s1[2] = {S[2], S[3]}, s2[2] = {S[4], S[5]};
+            uint32_t t0[2], t1[2], t2[2], u[2], v[2];
+            mont_mul<2>(t0, s0, onep, P);
+            mont_mul<2>(t1, s1, oneR, P);
+            mont_mul<2>(t2, s2, r2, P);
+            mod_add<2>(u, t0, t1, P);
+            mod_add<2>(v, u, t2, P);
+            Cm[r * n + c] = make_uint2(v[0], v[1]);
+        }
+}
+
 }  // namespace fpgpu
