@@ -63,6 +63,8 @@ void Launch<N>::batch_inv(const fpgpu_ctx* ctx, const void* x, void* out, uint8_
     auto X = [&](int l) -> const uint32_t* { return l == 0 ? (const uint32_t*)x : (const uint32_t*)(ws + p.x_off[l]); };
     auto O = [&](int l) -> uint32_t* { return l == 0 ? (uint32_t*)out : (uint32_t*)(ws + p.o_off[l]); };
     uint8_t* poisoned = (uint8_t*)(ws + p.poison_off);
+    uint32_t* any_poisoned = (uint32_t*)(ws + p.any_off);
+    (void)hipMemsetAsync(any_poisoned, 0, sizeof(uint32_t), s);
     // up-sweeps
     for (int l = 0; l < p.levels; l++) {
         int blocks = (int)((p.count[l] + tile - 1) / tile);
@@ -79,7 +81,7 @@ void Launch<N>::batch_inv(const fpgpu_ctx* ctx, const void* x, void* out, uint8_
         size_t c = p.count[p.levels];
         int blocks = (int)((c + kBlock - 1) / kBlock);
         hipLaunchKernelGGL((k_binv_top<N>), dim3(blocks), dim3(kBlock), 0, s, (uint32_t*)(ws + p.x_off[p.levels]),
-                           poisoned, c, P);
+                           poisoned, any_poisoned, c, P);
     }
     // down-sweeps
     for (int l = p.levels - 1; l >= 0; l--) {
@@ -95,7 +97,7 @@ void Launch<N>::batch_inv(const fpgpu_ctx* ctx, const void* x, void* out, uint8_
     }
     // composite-modulus safety net (a no-op unless a top-level total was not invertible)
     hipLaunchKernelGGL((k_binv_fallback<N, kInvC>), dim3(grid_for(n)), dim3(kBlock), 0, s, (const uint32_t*)x,
-                       (uint32_t*)out, flags, poisoned, n, p.levels, P);
+                       (uint32_t*)out, flags, poisoned, any_poisoned, n, p.levels, P);
 }
 
 template <int N>

@@ -26,7 +26,8 @@ constexpr int kMMTile = 16;   // k_matmul output tile edge
 
 // Batch-inversion level plan (shared by the workspace-size query and the launcher).
 constexpr int kInvC = 8;          // chain length per lane
-constexpr size_t kInvTop = 1024;  // stop recursing when this few totals remain
+constexpr size_t kInvTop = 32768; // stop recursing when this few totals remain: one exact inversion per lane
+                                  // costs the same latency for 512 or 32768 lanes, two tree levels do not
 constexpr int kInvMaxLevels = 16;
 struct InvPlan {
     int levels = 0;                         // number of up-sweeps
@@ -34,6 +35,7 @@ struct InvPlan {
     size_t x_off[kInvMaxLevels + 1] = {0};  // byte offset of X_l (l >= 1) in the workspace
     size_t o_off[kInvMaxLevels + 1] = {0};  // byte offset of O_l (1 <= l < levels)
     size_t poison_off = 0;
+    size_t any_off = 0;                      // one word: did any top-level inversion fail
     size_t bytes = 0;
 };
 InvPlan make_inv_plan(uint32_t n64, size_t n);

@@ -92,6 +92,7 @@ InvPlan make_inv_plan(uint32_t n64, size_t n) {
     for (int l = 1; l <= p.levels; l++) p.x_off[l] = take(p.count[l] * esz);
     for (int l = 1; l < p.levels; l++) p.o_off[l] = take(p.count[l] * esz);
     p.poison_off = take(p.count[p.levels]);
+    p.any_off = take(sizeof(uint32_t));
     p.bytes = off;
     return p;
 }
