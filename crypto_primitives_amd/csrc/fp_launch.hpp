@@ -21,7 +21,10 @@ namespace fpgpu {
 
 enum Op : int { OP_MUL = 0, OP_SQR = 1, OP_ADD = 2, OP_SUB = 3, OP_NEG = 4, OP_TO_MONT = 5, OP_FROM_MONT = 6 };
 
-constexpr int kBlock = 256;   // threads per workgroup of every streaming kernel (4 waves)
+#ifndef FPGPU_BLOCK
+#define FPGPU_BLOCK 256
+#endif
+constexpr int kBlock = FPGPU_BLOCK;   // threads per workgroup of every streaming kernel (4 waves)
 constexpr int kMMTile = 16;   // k_matmul output tile edge
 
 // Batch-inversion level plan (shared by the workspace-size query and the launcher).

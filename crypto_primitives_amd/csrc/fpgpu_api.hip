@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -69,10 +70,14 @@ uint64_t neg_inv64(uint64_t m0) {
 namespace fpgpu {
 
 int grid_for(size_t n) {
-    // HBM-streaming kernels: enough workgroups to fill 256 CUs x 8, grid-stride the
-    // rest (tools/ubench_hbm.hip: 8192-16384 workgroups is the sweet spot on MI355X).
+    // One element per lane up to 2^20 workgroups, grid-stride beyond.  Measured on the
+    // 2^28-element BN254 mul (MI355X): cap 2048 4.99 TB/s, 16384 5.22, 65536 5.38,
+    // 2^20 (no striding) 5.67-5.77, 2^22 5.68: short-lived workgroups keep the memory
+    // pipeline fuller than long grid-stride loops for these VALU-heavy streams.
     size_t blocks = (n + kBlock - 1) / kBlock;
-    return (int)std::min<size_t>(std::max<size_t>(blocks, 1), 16384);
+    size_t cap = (size_t)1 << 20;
+    if (const char* e = getenv("FPGPU_GRID_CAP")) { long v = atol(e); if (v > 0) cap = (size_t)v; }  // tuning only
+    return (int)std::min<size_t>(std::max<size_t>(blocks, 1), cap);
 }
 
 
