@@ -34,6 +34,13 @@ SIGNATURES = {
     "fpgpu_matvec_dev": (_int, [_vp, _vp, _sz, _sz, _vp, _vp, _vp]),
     "fpgpu_matmul_dev": (_int, [_vp, _vp, _vp, _vp, _sz, _sz, _sz, _vp]),
     "fpgpu_fill_random_dev": (_int, [_vp, _vp, _sz, _u64, _vp]),
+    "fpgpu_pow_dev": (_int, [_vp, _vp, _vp, _u32, _vp, _sz, _vp]),
+    "fpgpu_fold_workspace_bytes": (_sz, [_vp]),
+    "fpgpu_sum_dev": (_int, [_vp, _vp, _sz, _vp, _vp, _sz, _vp]),
+    "fpgpu_product_dev": (_int, [_vp, _vp, _sz, _vp, _vp, _sz, _vp]),
+    "fpgpu_pow": (_int, [_vp, _vp, _vp, _u32, _vp, _sz]),
+    "fpgpu_sum": (_int, [_vp, _vp, _sz, _vp]),
+    "fpgpu_product": (_int, [_vp, _vp, _sz, _vp]),
     "fpgpu_mul": (_int, [_vp, _vp, _vp, _vp, _sz]),
     "fpgpu_sqr": (_int, [_vp, _vp, _vp, _sz]),
     "fpgpu_add": (_int, [_vp, _vp, _vp, _vp, _sz]),

@@ -153,6 +153,33 @@ void Launch<N>::fill_random(const fpgpu_ctx* ctx, void* out, size_t n, uint64_t 
                        make_params<N>(ctx));
 }
 
+template <int N>
+void Launch<N>::pow(const fpgpu_ctx* ctx, const void* a, const uint32_t* exp32, int top_bit, void* out, size_t n,
+                    hipStream_t s) {
+    PowExp e;
+    for (int i = 0; i < 16; i++) e.w[i] = exp32[i];
+    e.top = top_bit;
+    hipLaunchKernelGGL((k_pow<N>), dim3(grid_for(n)), dim3(kBlock), 0, s, (const uint32_t*)a, (uint32_t*)out, n, e,
+                       make_params<N>(ctx));
+}
+
+template <int N>
+void Launch<N>::fold(bool product, const fpgpu_ctx* ctx, const void* v, size_t n, void* out, void* ws,
+                     hipStream_t s) {
+    size_t blocks = (n + kBlock - 1) / kBlock;
+    if (blocks > (size_t)kFoldBlocks) blocks = kFoldBlocks;
+    if (blocks < 1) blocks = 1;
+    const FpParams<N> P = make_params<N>(ctx);
+    // pass 1: slices -> partials (straight to `out` when one workgroup covers everything)
+    uint32_t* p1 = blocks == 1 ? (uint32_t*)out : (uint32_t*)ws;
+    if (product) hipLaunchKernelGGL((k_fold<N, true>), dim3((unsigned)blocks), dim3(kBlock), 0, s, (const uint32_t*)v, n, p1, P);
+    else hipLaunchKernelGGL((k_fold<N, false>), dim3((unsigned)blocks), dim3(kBlock), 0, s, (const uint32_t*)v, n, p1, P);
+    if (blocks > 1) {
+        if (product) hipLaunchKernelGGL((k_fold<N, true>), dim3(1), dim3(kBlock), 0, s, (const uint32_t*)ws, blocks, (uint32_t*)out, P);
+        else hipLaunchKernelGGL((k_fold<N, false>), dim3(1), dim3(kBlock), 0, s, (const uint32_t*)ws, blocks, (uint32_t*)out, P);
+    }
+}
+
 template struct Launch<FPGPU_N>;
 
 }  // namespace fpgpu

@@ -525,6 +525,94 @@ __global__ __launch_bounds__(kMMTile* kMMTile) void k_matmul(const uint32_t* __r
 }
 
 
+// ---- batched pow with one exponent for the whole batch ---------------
+// SemiringConfig::pow_u32 / FieldConfig::pow (crypto_bigint_monty.rs:163-172,239-249;
+// helpers/crypto_bigint.rs:220-455, a 4-bit-window "almost Montgomery" ladder).  The result
+// is the canonical residue x^e in Montgomery form whatever the ladder, so this uses plain
+// left-to-right square-and-multiply: the exponent is wave-uniform (kernel argument), every
+// branch on its bits is scalar.  x^0 = 1 (also 0^0), as the reference.
+struct PowExp {
+    uint32_t w[16];  // exponent, 32-bit little-endian limbs
+    int top;         // index of its highest set bit, -1 if the exponent is zero
+};
+template <int N>
+__global__ __launch_bounds__(kBlock) void k_pow(const uint32_t* __restrict__ a, uint32_t* __restrict__ out, size_t n,
+                                                const PowExp e, const FpParams<N> P) {
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        uint32_t x[N], acc[N], t[N];
+        load_elem<N>(x, a, i);
+        if (e.top < 0) {
+            set_limbs<N>(acc, P.one);
+        } else {
+#pragma unroll
+            for (int l = 0; l < N; l++) acc[l] = x[l];
+            for (int b = e.top - 1; b >= 0; b--) {
+                mont_mul<N>(t, acc, acc, P);
+#pragma unroll
+                for (int l = 0; l < N; l++) acc[l] = t[l];
+                if ((e.w[b >> 5] >> (b & 31)) & 1u) {
+                    mont_mul<N>(t, acc, x, P);
+#pragma unroll
+                    for (int l = 0; l < N; l++) acc[l] = t[l];
+                }
+            }
+        }
+        store_elem<N>(out, i, acc);
+    }
+}
+
+// ---- sum / product folds (SemiringConfig::sum_refs / product_refs,
+// src/semiring.rs:213-241: left folds from zero / one; the canonical result does not depend
+// on the association, so this is a tree).  One partial per workgroup; run twice (slices ->
+// partials, partials -> result).
+template <int N, bool PROD>
+__device__ __forceinline__ void fold2(uint32_t (&acc)[N], const uint32_t (&o)[N], const FpParams<N>& P) {
+    uint32_t r[N];
+    if constexpr (PROD) mont_mul<N>(r, acc, o, P);
+    else mod_add<N>(r, acc, o, P);
+#pragma unroll
+    for (int l = 0; l < N; l++) acc[l] = r[l];
+}
+template <int N, bool PROD>
+__global__ __launch_bounds__(kBlock) void k_fold(const uint32_t* __restrict__ v, size_t n,
+                                                 uint32_t* __restrict__ partials, const FpParams<N> P) {
+    __shared__ uint32_t part[kBlock / 64][N];
+    uint32_t acc[N], o[N];
+    if constexpr (PROD) set_limbs<N>(acc, P.one);
+    else {
+#pragma unroll
+        for (int l = 0; l < N; l++) acc[l] = 0;
+    }
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        load_elem<N>(o, v, i);
+        fold2<N, PROD>(acc, o, P);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+#pragma unroll
+        for (int l = 0; l < N; l++) o[l] = __shfl_down(acc[l], off, 64);
+        // lanes whose partner is past the wave read their own value back from __shfl_down;
+        // folding it would double-count, so only lanes < off fold (the others' results are unused)
+        if ((threadIdx.x & 63) < off) fold2<N, PROD>(acc, o, P);
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) {
+#pragma unroll
+        for (int l = 0; l < N; l++) part[wave][l] = acc[l];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kBlock / 64; w++) {
+#pragma unroll
+            for (int l = 0; l < N; l++) o[l] = part[w][l];
+            fold2<N, PROD>(acc, o, P);
+        }
+        store_elem<N>(partials, blockIdx.x, acc);
+    }
+}
+
 // ---- single-limb (n64 = 1, N = 2) mat-mul: register-tiled, lazily reduced -------------
 // BASELINE.json configs[4]: MontyField 64-bit prime (Goldilocks-size) 8192^2 mat-mul.
 // Workgroup = 256 lanes computing a 64 x 32 tile of C; lane (ty, tx) owns 4 x 2 outputs.

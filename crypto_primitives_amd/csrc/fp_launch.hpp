@@ -42,6 +42,7 @@ struct InvPlan {
     size_t bytes = 0;
 };
 InvPlan make_inv_plan(uint32_t n64, size_t n);
+constexpr int kFoldBlocks = 2048;  // partials of the first fold pass (workspace = kFoldBlocks elements)
 int grid_for(size_t n);
 
 template <int N>
@@ -57,6 +58,10 @@ struct Launch {
     static void matmul(const fpgpu_ctx* ctx, const void* A, const void* B, void* C, size_t m, size_t k, size_t n,
                        hipStream_t s);
     static void fill_random(const fpgpu_ctx* ctx, void* out, size_t n, uint64_t seed, hipStream_t s);
+    static void pow(const fpgpu_ctx* ctx, const void* a, const uint32_t* exp32, int top_bit, void* out, size_t n,
+                    hipStream_t s);
+    static void fold(bool product, const fpgpu_ctx* ctx, const void* v, size_t n, void* out, void* ws,
+                     hipStream_t s);
 };
 
 extern template struct Launch<2>;

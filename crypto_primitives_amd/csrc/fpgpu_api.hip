@@ -325,6 +325,60 @@ int fpgpu_matmul_dev(const fpgpu_ctx* ctx, const void* A, const void* B, void* C
     return FPGPU_OK;
 }
 
+int fpgpu_pow_dev(const fpgpu_ctx* ctx, const void* a, const uint64_t* exponent_le, uint32_t exponent_words, void* out,
+                  size_t n, void* stream) {
+    CHECK(check_common(ctx, n));
+    if (exponent_words > 8) return fail(FPGPU_ERR_UNSUPPORTED, "pow: exponent wider than 512 bits");
+    if (exponent_words && !exponent_le) return fail(FPGPU_ERR_SHAPE, "null pointer: exponent");
+    if (n == 0) return FPGPU_OK;
+    CHECK(check_ptr(ctx, a, "a"));
+    CHECK(check_ptr(ctx, out, "out"));
+    uint32_t e32[16] = {0};
+    int top = -1;
+    for (uint32_t i = 0; i < exponent_words; i++) {
+        e32[2 * i] = (uint32_t)exponent_le[i];
+        e32[2 * i + 1] = (uint32_t)(exponent_le[i] >> 32);
+        if (exponent_le[i]) top = 64 * (int)i + 63 - __builtin_clzll(exponent_le[i]);
+    }
+    hipStream_t s = (hipStream_t)stream;
+    DISPATCH_N64(ctx->n64, Launch<N>::pow(ctx, a, e32, top, out, n, s));
+    HIP_TRY(hipGetLastError());
+    return FPGPU_OK;
+}
+
+size_t fpgpu_fold_workspace_bytes(const fpgpu_ctx* ctx) {
+    return ctx ? (size_t)kFoldBlocks * ctx->n64 * 8 : 0;
+}
+
+static int fold_dev(bool product, const fpgpu_ctx* ctx, const void* v, size_t n, void* out, void* workspace,
+                    size_t workspace_bytes, void* stream) {
+    CHECK(check_common(ctx, n));
+    CHECK(check_ptr(ctx, out, "out"));
+    hipStream_t s = (hipStream_t)stream;
+    if (n == 0) {  // empty fold: the identity (sum -> zero, product -> one), src/semiring.rs:213-241
+        const uint64_t zero[FPGPU_MAX_N64] = {0};
+        HIP_TRY(hipMemcpyAsync(out, product ? ctx->one : zero, ctx->n64 * 8, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipStreamSynchronize(s));  // the source is on this call's stack / in the context
+        return FPGPU_OK;
+    }
+    CHECK(check_ptr(ctx, v, "v"));
+    if (n > (size_t)kBlock) {
+        if (!workspace || (uintptr_t)workspace % 16) return fail(FPGPU_ERR_SHAPE, "fold: workspace null or misaligned");
+        if (workspace_bytes < fpgpu_fold_workspace_bytes(ctx)) return fail(FPGPU_ERR_SHAPE, "fold: workspace too small");
+    }
+    DISPATCH_N64(ctx->n64, Launch<N>::fold(product, ctx, v, n, out, workspace, s));
+    HIP_TRY(hipGetLastError());
+    return FPGPU_OK;
+}
+int fpgpu_sum_dev(const fpgpu_ctx* ctx, const void* v, size_t n, void* out, void* workspace, size_t workspace_bytes,
+                  void* stream) {
+    return fold_dev(false, ctx, v, n, out, workspace, workspace_bytes, stream);
+}
+int fpgpu_product_dev(const fpgpu_ctx* ctx, const void* v, size_t n, void* out, void* workspace,
+                      size_t workspace_bytes, void* stream) {
+    return fold_dev(true, ctx, v, n, out, workspace, workspace_bytes, stream);
+}
+
 int fpgpu_fill_random_dev(const fpgpu_ctx* ctx, void* out, size_t n, uint64_t seed, void* stream) {
     CHECK(check_common(ctx, n));
     if (n == 0) return FPGPU_OK;
@@ -369,6 +423,33 @@ int fpgpu_mul_chain(const fpgpu_ctx* ctx, const uint64_t* a, const uint64_t* b, 
     return host_binary(ctx, a, b, out, n, true, [&](void* da, void* db, void* dout) {
         return fpgpu_mul_chain_dev(ctx, da, db, dout, n, iters, nullptr);
     });
+}
+
+int fpgpu_pow(const fpgpu_ctx* ctx, const uint64_t* a, const uint64_t* exponent_le, uint32_t exponent_words,
+              uint64_t* out, size_t n) {
+    return host_binary(ctx, a, nullptr, out, n, false, [&](void* da, void*, void* dout) {
+        return fpgpu_pow_dev(ctx, da, exponent_le, exponent_words, dout, n, nullptr);
+    });
+}
+
+static int fold_host(bool product, const fpgpu_ctx* ctx, const uint64_t* v, size_t n, uint64_t* out) {
+    CHECK(check_common(ctx, n));
+    if (!out || (n && !v)) return fail(FPGPU_ERR_SHAPE, "null host pointer");
+    CHECK(require_device());
+    size_t esz = ctx->n64 * 8;
+    DevBuf dv, dout, ws;
+    CHECK(dv.alloc(n * esz));
+    CHECK(dout.alloc(esz));
+    CHECK(ws.alloc(fpgpu_fold_workspace_bytes(ctx)));
+    if (n) HIP_TRY(hipMemcpy(dv.p, v, n * esz, hipMemcpyHostToDevice));
+    CHECK(fold_dev(product, ctx, dv.p, n, dout.p, ws.p, fpgpu_fold_workspace_bytes(ctx), nullptr));
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    HIP_TRY(hipMemcpy(out, dout.p, esz, hipMemcpyDeviceToHost));
+    return FPGPU_OK;
+}
+int fpgpu_sum(const fpgpu_ctx* ctx, const uint64_t* v, size_t n, uint64_t* out) { return fold_host(false, ctx, v, n, out); }
+int fpgpu_product(const fpgpu_ctx* ctx, const uint64_t* v, size_t n, uint64_t* out) {
+    return fold_host(true, ctx, v, n, out);
 }
 
 int fpgpu_batch_inv(const fpgpu_ctx* ctx, const uint64_t* x, uint64_t* out, uint8_t* zero_flags, size_t n) {

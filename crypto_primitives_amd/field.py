@@ -103,6 +103,27 @@ class MontyField:
         check(self._lib.fpgpu_mul_chain(self._h, _ptr(a), _ptr(b), _ptr(out), a.shape[0], iters))
         return out
 
+    def pow(self, a, exponent: int):
+        """Batch FieldConfig::pow / pow_u32: a[i]^exponent, one exponent for the whole batch."""
+        a = _np(a, self.n64)
+        nw = max(1, (exponent.bit_length() + 63) // 64)
+        ew = np.array([(exponent >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(nw)], dtype=np.uint64)
+        out = np.empty_like(a)
+        check(self._lib.fpgpu_pow(self._h, _ptr(a), _ptr(ew), nw, _ptr(out), a.shape[0]))
+        return out
+
+    def sum(self, v):
+        v = _np(v, self.n64)
+        out = np.zeros(self.n64, dtype=np.uint64)
+        check(self._lib.fpgpu_sum(self._h, _ptr(v) if v.shape[0] else None, v.shape[0], _ptr(out)))
+        return out
+
+    def product(self, v):
+        v = _np(v, self.n64)
+        out = np.zeros(self.n64, dtype=np.uint64)
+        check(self._lib.fpgpu_product(self._h, _ptr(v) if v.shape[0] else None, v.shape[0], _ptr(out)))
+        return out
+
     def inv(self, x):
         """Batch FieldConfig::inv.  Returns (out, none_flags): none_flags[i] = 1 where the
         reference returns None (out[i] = 0 there)."""

@@ -91,6 +91,23 @@ int fpgpu_from_mont_dev(const fpgpu_ctx *ctx, const void *a, void *out, size_t n
 int fpgpu_mul_chain_dev(const fpgpu_ctx *ctx, const void *a, const void *b, void *out, size_t n,
                         uint32_t iters, void *stream);
 
+/* ---- rows SURVEY.md section 8f marks "next" ------------------------------------
+ * Batched SemiringConfig::pow_u32 / FieldConfig::pow with ONE exponent for the whole
+ * batch (crypto_bigint_monty.rs:163-172,239-249; the 4-bit-window almost-Montgomery
+ * ladder of src/helpers/crypto_bigint.rs:220-455): out[i] = a[i]^e in Montgomery form,
+ * fully reduced; e == 0 gives one (also for a[i] == 0).  `exponent_le` is a HOST array
+ * of `exponent_words` (<= 8) little-endian 64-bit words. */
+int fpgpu_pow_dev(const fpgpu_ctx *ctx, const void *a, const uint64_t *exponent_le, uint32_t exponent_words,
+                  void *out, size_t n, void *stream);
+/* SemiringConfig::sum_refs / product_refs (src/semiring.rs:213-241): folds of add / mul
+ * over v[0..n); the empty fold is zero / one.  `out` is ONE element (device).
+ * `workspace`: fpgpu_fold_workspace_bytes(ctx) bytes of device scratch (needed when n > 256). */
+size_t fpgpu_fold_workspace_bytes(const fpgpu_ctx *ctx);
+int fpgpu_sum_dev(const fpgpu_ctx *ctx, const void *v, size_t n, void *out, void *workspace,
+                  size_t workspace_bytes, void *stream);
+int fpgpu_product_dev(const fpgpu_ctx *ctx, const void *v, size_t n, void *out, void *workspace,
+                      size_t workspace_bytes, void *stream);
+
 /* ---- batch inversion -------------------------------------------------------
  * out[i] = FieldConfig::inv(x[i]) (crypto_bigint_monty.rs:223-237,
  * boxed_monty.rs:273-284, const_monty.rs:277-283) for every i, computed with
@@ -128,6 +145,10 @@ int fpgpu_to_mont(const fpgpu_ctx *ctx, const uint64_t *a, uint64_t *out, size_t
 int fpgpu_from_mont(const fpgpu_ctx *ctx, const uint64_t *a, uint64_t *out, size_t n);
 int fpgpu_mul_chain(const fpgpu_ctx *ctx, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t n,
                     uint32_t iters);
+int fpgpu_pow(const fpgpu_ctx *ctx, const uint64_t *a, const uint64_t *exponent_le, uint32_t exponent_words,
+              uint64_t *out, size_t n);
+int fpgpu_sum(const fpgpu_ctx *ctx, const uint64_t *v, size_t n, uint64_t *out);
+int fpgpu_product(const fpgpu_ctx *ctx, const uint64_t *v, size_t n, uint64_t *out);
 int fpgpu_batch_inv(const fpgpu_ctx *ctx, const uint64_t *x, uint64_t *out, uint8_t *zero_flags, size_t n);
 int fpgpu_matvec(const fpgpu_ctx *ctx, const uint64_t *A, size_t rows, size_t cols, const uint64_t *x,
                  uint64_t *y);

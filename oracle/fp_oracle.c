@@ -545,6 +545,97 @@ void fpo_bench_mul_assign(const word *modulus, size_t n, const word *elem, size_
     memcpy(out, acc, n * sizeof(word));
 }
 
+/* ======================= pow =====================
+ * ---- src/helpers/crypto_bigint.rs:441-454 conditional_borrowing_sub_assign */
+static int conditional_borrowing_sub_assign(word *lhs, const word *rhs, int choice, size_t n)
+{
+    word mask = choice ? ~(word)0 : 0, borrow = 0;
+    for (size_t i = 0; i < n; i++) {
+        wide t = (wide)lhs[i] - (wide)(rhs[i] & mask) - (wide)borrow;
+        lhs[i] = (word)t;
+        borrow = (word)((t >> 64) & 1);
+    }
+    return (int)borrow;
+}
+/* ---- :413-426 almost_montgomery_mul: out = x*y/R reduced to the bit length of the
+ * modulus (may still exceed it). */
+static void almost_montgomery_mul(const word *x, const word *y, word *out, const word *modulus,
+                                  word mod_neg_inv, size_t n)
+{
+    memset(out, 0, n * sizeof(word));
+    word overflow = fpo_monty_mul_limbs(x, y, out, modulus, mod_neg_inv, n);
+    conditional_borrowing_sub_assign(out, modulus, (int)(overflow & 1), n);
+}
+/* ---- :436-439 almost_montgomery_reduce: two conditional subtractions */
+static void almost_montgomery_reduce(word *z, const word *modulus, size_t n)
+{
+    conditional_borrowing_sub_assign(z, modulus, cmp_n(z, modulus, n) >= 0, n);
+    conditional_borrowing_sub_assign(z, modulus, cmp_n(z, modulus, n) >= 0, n);
+}
+/* ---- :239-315 pow_montgomery_form_amm + :336-361 pow_bounded_exp: 4-bit fixed window,
+ * "almost Montgomery" multiplications, fully reduced result in Montgomery form.
+ * exponent: little-endian 64-bit limbs; exponent_bits: how many low bits count. */
+void fpo_pow_bounded_exp(const word *x, const word *exponent, uint32_t exponent_bits, const word *one,
+                         const word *modulus, word mod_neg_inv, word *out, size_t n)
+{
+    enum { WINDOW = 4, WINDOW_COUNT = 16, BITS_PER_WINDOW = 64 / 4 };
+    if (exponent_bits == 0) { memcpy(out, one, n * sizeof(word)); return; }
+    word powers[WINDOW_COUNT][FPO_MAX_LIMBS], prod[FPO_MAX_LIMBS], z[FPO_MAX_LIMBS], power[FPO_MAX_LIMBS];
+    /* powers[i] = x^i (:258-270) */
+    memcpy(powers[0], one, n * sizeof(word));
+    memcpy(powers[1], x, n * sizeof(word));
+    for (int i = 2; i < WINDOW_COUNT; i++) {
+        almost_montgomery_mul(powers[i - 1], x, prod, modulus, mod_neg_inv, n);
+        memcpy(powers[i], prod, n * sizeof(word));
+    }
+    /* pow_init (:428-434) */
+    uint32_t starting_limb = (exponent_bits - 1) / 64;
+    uint32_t starting_bit_in_limb = (exponent_bits - 1) % 64;
+    uint32_t starting_window = starting_bit_in_limb / WINDOW;
+    word starting_window_mask = ((word)1 << (starting_bit_in_limb % WINDOW + 1)) - 1;
+    memcpy(z, one, n * sizeof(word));
+    for (int limb_num = (int)starting_limb; limb_num >= 0; limb_num--) {
+        word w = exponent[limb_num];
+        uint32_t window_num = (uint32_t)limb_num == starting_limb ? starting_window + 1 : BITS_PER_WINDOW;
+        while (window_num > 0) {
+            window_num--;
+            word idx = (w >> (window_num * WINDOW)) & 15;
+            if ((uint32_t)limb_num == starting_limb && window_num == starting_window) {
+                idx &= starting_window_mask;
+            } else {
+                for (int sq = 0; sq < WINDOW; sq++) {
+                    almost_montgomery_mul(z, z, prod, modulus, mod_neg_inv, n);
+                    memcpy(z, prod, n * sizeof(word));
+                }
+            }
+            memcpy(power, powers[idx], n * sizeof(word));
+            almost_montgomery_mul(z, power, prod, modulus, mod_neg_inv, n);
+            memcpy(z, prod, n * sizeof(word));
+        }
+    }
+    almost_montgomery_reduce(z, modulus, n);
+    memcpy(out, z, n * sizeof(word));
+}
+/* Batch: one exponent for every element (MontyField::pow_u32 / ::pow,
+ * src/field/crypto_bigint_monty.rs:163-172,239-249). */
+int fpo_batch_pow(const word *modulus, size_t n, const word *x, const word *exponent, uint32_t exponent_bits,
+                  word *out, size_t count, int threads)
+{
+    word inv, one[FPO_MAX_LIMBS], r2[FPO_MAX_LIMBS];
+    if (fpo_params(modulus, n, &inv, one, r2)) return 1;
+    (void)threads;
+#ifdef _OPENMP
+    if (threads > 0) omp_set_num_threads(threads);
+#pragma omp parallel for schedule(static) if (threads != 1)
+#endif
+    for (ptrdiff_t i = 0; i < (ptrdiff_t)count; i++) {
+        word tmp[FPO_MAX_LIMBS];
+        fpo_pow_bounded_exp(x + (size_t)i * n, exponent, exponent_bits, one, modulus, inv, tmp, n);
+        memcpy(out + (size_t)i * n, tmp, n * sizeof(word));
+    }
+    return 0;
+}
+
 int fpo_max_threads(void)
 {
 #ifdef _OPENMP

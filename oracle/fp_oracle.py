@@ -146,6 +146,20 @@ class Oracle:
                          ctypes.c_size_t(m), ctypes.c_size_t(k), ctypes.c_size_t(n), ctypes.c_int(threads))
         return C
 
+    def pow(self, x, exponent: int, exponent_bits=None, threads=1):
+        """x[i]^exponent for every i (one exponent for the batch), as pow_bounded_exp does it."""
+        x = _arr(x, self.n64)
+        if exponent_bits is None:
+            exponent_bits = 64 * self.n64
+        nw = max(1, (exponent_bits + 63) // 64)
+        ew = int_to_words(exponent & ((1 << (64 * nw)) - 1), nw)
+        out = np.empty_like(x)
+        rc = lib().fpo_batch_pow(_p(self.mod), ctypes.c_size_t(self.n64), _p(x), _p(ew),
+                                 ctypes.c_uint32(exponent_bits), _p(out), ctypes.c_size_t(x.shape[0]),
+                                 ctypes.c_int(threads))
+        assert rc == 0
+        return out
+
     def bench_mul_assign(self, elem, iters):
         elem = _arr(elem).reshape(-1)
         out = np.zeros(self.n64, dtype=np.uint64)

@@ -257,6 +257,51 @@ def test_matmul_vs_oracle(cpa, shape):
         assert np.array_equal(f.matmul(A, B, m, k, n), o.matmul(A, B, m, k, n, threads=0))
 
 
+@pytest.mark.parametrize("name", ["bn254_fr", "goldilocks", "bls12_381_fq", "odd_composite_128"])
+def test_pow_vs_oracle(cpa, name):
+    # batched pow, one exponent per batch; oracle = the reference's 4-bit-window AMM ladder
+    g = load_golden(name)
+    f, o = field_of(cpa, g), oracle_of(g)
+    p, n64 = h2i(g["modulus"]), g["n64"]
+    rnd = random.Random(11)
+    xs = [0, 1, p - 1, p - 2] + [rnd.randrange(p) for _ in range(300)]
+    x = o.to_mont(ints_to_array(xs, n64))
+    for e in [0, 1, 2, 3, 15, 16, 17, 2**32 - 1, 2**64 - 1, 2**64, p - 2, p - 1, rnd.getrandbits(64 * n64)]:
+        bits = max(64 * n64, 64 * ((e.bit_length() + 63) // 64))
+        want = o.pow(x, e, exponent_bits=bits)
+        got = f.pow(x, e)
+        assert (got == want).all(), (name, hex(e))
+    assert f.pow(x[:0], 5).shape == (0, n64)
+
+
+def test_pow_u32_reference_kats(cpa):
+    # crypto_bigint_monty.rs:726-760, 934-1004 through the GPU path
+    f = cpa.MontyField(2**256 - 2**32 - 977, 4)
+    pr = lambda v: f.project(ints_to_array([v], 4))
+    for base, e, r in [(2, 0, 1), (2, 1, 2), (2, 3, 8), (2, 10, 1024), (3, 4, 81), (0, 0, 1), (0, 7, 0)]:
+        assert (f.pow(pr(base), e) == pr(r)).all(), (base, e)
+    g = cpa.MontyField(10064419296686275259, 1)
+    pg = lambda v: g.project(ints_to_array([v], 1))
+    for base, e in [(2, 8), (2, 9), (3, 5), (12345, 67), (2, 64), (123456789, 2**32 - 1)]:
+        assert array_to_ints(g.lift(g.pow(pg(base), e)))[0] == pow(base, e, 10064419296686275259)
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 63, 64, 65, 256, 257, 4099, 600001])
+def test_sum_product_vs_oracle(cpa, n):
+    # SemiringConfig::sum_refs / product_refs (src/semiring.rs:213-241)
+    for name in ["bn254_fr", "goldilocks", "bls12_381_fq"]:
+        g = load_golden(name)
+        f, o = field_of(cpa, g), oracle_of(g)
+        p, n64 = h2i(g["modulus"]), g["n64"]
+        v = np.random.default_rng(n + 3).integers(0, 2**64, size=(n, n64), dtype=np.uint64)
+        top = p.bit_length() - 1 - 64 * (n64 - 1)      # keep every element below 2^(bitlen-1) < p
+        v[:, n64 - 1] &= np.uint64((1 << top) - 1)
+        if n > 2:
+            v[1] = ints_to_array([p - 1], n64)[0]
+        assert (f.sum(v) == o.sum(v)).all(), (name, n, "sum")
+        assert (f.product(v) == o.product(v)).all(), (name, n, "product")
+
+
 def test_fill_random_matches_host_generator(cpa):
     import torch
     for name in ("bn254_fr", "bls12_381_fq", "goldilocks"):

@@ -187,3 +187,52 @@ def test_mod_neg_inv_newton_matches_definition():
     from oracle.fp_oracle import lib
     for m0 in (1, 3, 0xFFFFFFFFFFFFFFFF, 0x43E1F593F0000001, 0xB9FEFFFFFFFFAAAB, 0xFFFFFFFF00000001):
         assert lib().fpo_mod_neg_inv(ctypes.c_uint64(m0)) == (-pow(m0, -1, 1 << 64)) % (1 << 64)
+
+
+def _pow_both(f, x, e, n64):
+    """pow_u32 walks 32 exponent bits, pow(&Uint) walks Uint::BITS (crypto_bigint_monty.rs:163-172,
+    239-249); both must agree."""
+    a = f.o.pow(f._a(x), e, exponent_bits=32)
+    b = f.o.pow(f._a(x), e, exponent_bits=64 * n64)
+    assert (a == b).all()
+    return f._i(a)
+
+
+def test_pow_operation(f):
+    # crypto_bigint_monty.rs:726-760 (also boxed_monty.rs:713, const_monty.rs:1270)
+    two, three = f.project(2), f.project(3)
+    assert _pow_both(f, two, 0, 4) == f.one()
+    assert _pow_both(f, two, 1, 4) == two
+    assert _pow_both(f, two, 3, 4) == f.project(8)
+    assert _pow_both(f, two, 10, 4) == f.project(1024)
+    assert _pow_both(f, three, 4, 4) == f.project(81)
+
+
+def test_pow_matches_definition(f):
+    # crypto_bigint_monty.rs:934-971 compares with crypto-bigint's FixedMontyForm::pow (crate absent
+    # here, pinned 0.7.0-rc in Cargo.toml); that value is base^exp mod p, so Python's pow pins it.
+    for base, e in [(0, 0), (0, 7), (1, 1000), (2, 10), (3, 251), (123456789, 1), (123456789, 2**32 - 1)]:
+        assert f.lift(_pow_both(f, f.project(base), e, 4)) == pow(base, e, SECP), (base, e)
+    x = f.project(123456789)
+    got = f._i(f.o.pow(f._a(x), 2**128 - 1))
+    assert f.lift(got) == pow(123456789, 2**128 - 1, SECP)
+
+
+def test_pow_amm_final_reduction():
+    # crypto_bigint_monty.rs:978-1004: final AMM value in [p, 2p) needs exactly one subtraction
+    g = F(P64, 1)
+    for base, e, r in [(2, 8, 256), (2, 9, 512), (3, 5, 243)]:
+        assert g._i(g.o.pow(g._a(g.project(base)), e, exponent_bits=32)) == g.project(r)
+    for base, e in [(12345, 67), (2, 64), (123456789, 2**32 - 1)]:
+        assert g.lift(g._i(g.o.pow(g._a(g.project(base)), e, exponent_bits=32))) == pow(base, e, P64)
+
+
+def test_pow_random_against_definition():
+    import random
+    rnd = random.Random(5)
+    for p, n64 in [(SECP, 4), (P64, 1), (PROP, 4)]:
+        g = F(p, n64)
+        xs = [rnd.randrange(p) for _ in range(40)]
+        for e in [0, 1, 2, 15, 16, 17, 255, 2**31, p - 2, p - 1, rnd.getrandbits(64 * n64)]:
+            out = array_to_ints(g.o.pow(g.o.to_mont(ints_to_array(xs, n64)), e))
+            assert [g.lift(v) for v in out] == [pow(x, e, p) for x in xs]
