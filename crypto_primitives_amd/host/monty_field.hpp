@@ -329,6 +329,17 @@ class MontyField {
     void square_batch(const Element* a, Element* out, size_t n) const { fpgpu_check(fpgpu_sqr(ctx_.get(), p(a), p(out), n)); }
     void project_batch(const Integer* a, Element* out, size_t n) const { fpgpu_check(fpgpu_to_mont(ctx_.get(), a[0].words.data(), p(out), n)); }
     void lift_batch(const Element* a, Integer* out, size_t n) const { fpgpu_check(fpgpu_from_mont(ctx_.get(), p(a), out[0].words.data(), n)); }
+    // pow with one exponent for the whole batch (FieldConfig::pow, crypto_bigint_monty.rs:239-249)
+    void pow_batch(const Element* a, const Integer& exponent, Element* out, size_t n) const {
+        fpgpu_check(fpgpu_pow(ctx_.get(), p(a), exponent.words.data(), (uint32_t)LIMBS, p(out), n));
+    }
+    void pow_u32_batch(const Element* a, uint32_t exponent, Element* out, size_t n) const {
+        uint64_t e = exponent;
+        fpgpu_check(fpgpu_pow(ctx_.get(), p(a), &e, 1, p(out), n));
+    }
+    // SemiringConfig::sum_refs / product_refs over a contiguous slice (src/semiring.rs:213-241)
+    Element sum_batch(const Element* v, size_t n) const { Element r; fpgpu_check(fpgpu_sum(ctx_.get(), p(v), n, p(&r))); return r; }
+    Element product_batch(const Element* v, size_t n) const { Element r; fpgpu_check(fpgpu_product(ctx_.get(), p(v), n, p(&r))); return r; }
     std::vector<Element> mul_batch(const std::vector<Element>& a, const std::vector<Element>& b) const {
         if (a.size() != b.size()) throw std::invalid_argument("length mismatch");
         std::vector<Element> out(a.size());

@@ -185,6 +185,23 @@ static void test_gpu_batches() {
     for (size_t i = 0; i < n; i++) CHECK(lifted[i] == f.lift(a[i]));
     f.project_batch(lifted.data(), out.data(), n);
     for (size_t i = 0; i < n; i++) CHECK(out[i] == a[i]);
+    // pow (one exponent per batch) and the sum / product folds
+    f.pow_u32_batch(a.data(), 65537u, out.data(), n);
+    for (size_t i = 0; i < n; i += 97) CHECK(out[i] == f.pow_u32(a[i], 65537u));
+    Uint<4> big = f.lift(a[3]);
+    f.pow_batch(a.data(), big, out.data(), 64);
+    for (size_t i = 0; i < 64; i += 9) {
+        auto acc = f.one();
+        for (int bit = 255; bit >= 0; bit--) {
+            acc = f.mul(acc, acc);
+            if ((big.words[bit / 64] >> (bit % 64)) & 1) acc = f.mul(acc, a[i]);
+        }
+        CHECK(out[i] == acc);
+    }
+    CHECK(f.sum_batch(a.data(), n) == f.sum_refs(a.begin(), a.end()));
+    CHECK(f.product_batch(a.data(), n) == f.product_refs(a.begin(), a.end()));
+    CHECK(f.sum_batch(a.data(), 0) == f.zero());
+    CHECK(f.product_batch(a.data(), 0) == f.one());
     // mat-vec / mat-mul over DenseRowMatrix == folds of the scalar ops
     DenseRowMatrix<F::Element> A;
     A.num_rows = 9; A.num_cols = 300; A.data = random_elems(f, 9 * 300, 3);
