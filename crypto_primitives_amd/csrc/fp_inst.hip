@@ -3,6 +3,9 @@
 
 #include "fp_kernels.cuh"
 #include "fp_launch.hpp"
+#if FPGPU_N == 2
+#include "fp_matmul_mfma.cuh"
+#endif
 
 #ifndef FPGPU_N
 #error "compile with -DFPGPU_N=<number of 32-bit limbs>"
@@ -130,18 +133,43 @@ void Launch<N>::matvec(const fpgpu_ctx* ctx, const void* A, size_t rows, size_t 
 
 template <int N>
 void Launch<N>::matmul(const fpgpu_ctx* ctx, const void* A, const void* B, void* C, size_t m, size_t k, size_t n,
-                       hipStream_t s) {
-    if constexpr (N == 2) {
-        // single-limb fast path (register-tiled, lazily reduced); FPGPU_MATMUL_GENERIC=1 forces
-        // the generic kernel for A/B checks
+                       void* workspace, size_t workspace_bytes, hipStream_t s) {
+#if FPGPU_N == 2
+    {
+        // single-limb paths; FPGPU_MATMUL_GENERIC=1 forces the generic kernel, FPGPU_MATMUL_MFMA=0
+        // the VALU kernel (A/B checks and timing)
         const char* g = getenv("FPGPU_MATMUL_GENERIC");
         if (!(g && atoi(g))) {
-            size_t gx = (n + kMM1_BN - 1) / kMM1_BN, gy = (m + kMM1_BM - 1) / kMM1_BM;
+            const size_t gx = (n + kMM1_BN - 1) / kMM1_BN, gy = (m + kMM1_BM - 1) / kMM1_BM;
+            const MfmaPlan pl = make_mfma_plan(ctx->n64, m, k, n);
+            const char* e = getenv("FPGPU_MATMUL_MFMA");
+            const bool mfma = pl.usable && workspace && workspace_bytes >= pl.bytes && !(e && !atoi(e));
+            if (!mfma) {
+                hipLaunchKernelGGL((k_matmul_1limb<N>), dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, s,
+                                   (const uint2*)A, (const uint2*)B, (uint2*)C, m, k, n, (const uint32_t*)nullptr,
+                                   make_params<N>(ctx));
+                return;
+            }
+            uint8_t* ws = (uint8_t*)workspace;
+            uint32_t* flag = (uint32_t*)ws;
+            (void)hipMemsetAsync(flag, 0, 4, s);
+            const unsigned wa = pl.rblocks * pl.ksteps, wb = pl.cblocks * pl.ksteps;  // x4 waves = one workgroup each
+            hipLaunchKernelGGL((k_mf_digitize<false>), dim3(wa), dim3(256), 0, s, (const uint64_t*)A, m, k, k,
+                               ws + pl.a_off, pl.rblocks, pl.ksteps, ctx->modulus[0], flag);
+            hipLaunchKernelGGL((k_mf_digitize<true>), dim3(wb), dim3(256), 0, s, (const uint64_t*)B, n, k, n,
+                               ws + pl.b_off, pl.cblocks, pl.ksteps, ctx->modulus[0], flag);
+            const unsigned tiles = pl.rblocks * pl.cblocks, grid = (tiles + 7) / 8 * 8;
+            hipLaunchKernelGGL((k_matmul_mfma_1limb<N>), dim3(grid), dim3(256), 0, s, ws + pl.a_off, ws + pl.b_off,
+                               (uint2*)C, m, n, pl.rblocks, pl.cblocks, pl.ksteps, (const uint32_t*)flag,
+                               make_params<N>(ctx));
             hipLaunchKernelGGL((k_matmul_1limb<N>), dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, s, (const uint2*)A,
-                               (const uint2*)B, (uint2*)C, m, k, n, make_params<N>(ctx));
+                               (const uint2*)B, (uint2*)C, m, k, n, (const uint32_t*)flag, make_params<N>(ctx));
             return;
         }
     }
+#endif
+    (void)workspace;
+    (void)workspace_bytes;
     size_t gx = (n + kMMTile - 1) / kMMTile, gy = (m + kMMTile - 1) / kMMTile;
     hipLaunchKernelGGL((k_matmul<N>), dim3((unsigned)gx, (unsigned)gy), dim3(kMMTile * kMMTile), 0, s,
                        (const uint32_t*)A, (const uint32_t*)B, (uint32_t*)C, m, k, n, make_params<N>(ctx));

@@ -649,8 +649,10 @@ constexpr int kMM1_BM = 64, kMM1_BN = 32, kMM1_BK = 32, kMM1_TM = 4, kMM1_TN = 2
 template <int N>  // N == 2 only; a template so that each limb-count translation unit may include it
 __global__ __launch_bounds__(256) void k_matmul_1limb(const uint2* __restrict__ A, const uint2* __restrict__ B,
                                                       uint2* __restrict__ Cm, size_t m, size_t k, size_t n,
-                                                      const FpParams<N> P) {
+                                                      const uint32_t* __restrict__ run_if_set, const FpParams<N> P) {
     static_assert(N == 2, "single-limb kernel");
+    // as the fallback of k_matmul_mfma_1limb this runs only when the digitiser raised its flag
+    if (run_if_set && *run_if_set == 0) return;
     __shared__ uint2 sA[kMM1_BK][kMM1_BM];  // [k][row]
     __shared__ uint2 sB[kMM1_BK][kMM1_BN];  // [k][col]
     const int tid = threadIdx.x;

@@ -42,6 +42,25 @@ struct InvPlan {
     size_t bytes = 0;
 };
 InvPlan make_inv_plan(uint32_t n64, size_t n);
+// Workspace of the matrix-core mat-mul (fp_matmul_mfma.cuh): a flag word, then the int8 digit
+// planes of A and of B^T in 64-row blocks x 64-deep k-steps x 32 KiB.
+struct MfmaPlan {
+    bool usable;  // n64 == 1 shapes the int32 accumulators hold exactly
+    uint32_t rblocks, cblocks, ksteps;
+    size_t a_off, b_off, bytes;
+};
+inline MfmaPlan make_mfma_plan(uint32_t n64, size_t m, size_t k, size_t n) {
+    MfmaPlan pl{};
+    pl.usable = n64 == 1 && m > 0 && n > 0 && k > 0 && k <= 16320 && (m + 63) / 64 * ((n + 63) / 64) < (1u << 28);
+    if (!pl.usable) return pl;
+    pl.rblocks = (uint32_t)((m + 63) / 64);
+    pl.cblocks = (uint32_t)((n + 63) / 64);
+    pl.ksteps = (uint32_t)((k + 63) / 64);
+    pl.a_off = 256;
+    pl.b_off = pl.a_off + (size_t)pl.rblocks * pl.ksteps * 32768;
+    pl.bytes = pl.b_off + (size_t)pl.cblocks * pl.ksteps * 32768;
+    return pl;
+}
 constexpr int kFoldBlocks = 2048;  // partials of the first fold pass (workspace = kFoldBlocks elements)
 int grid_for(size_t n);
 
@@ -56,6 +75,7 @@ struct Launch {
     static void matvec(const fpgpu_ctx* ctx, const void* A, size_t rows, size_t cols, const void* x, void* y,
                        hipStream_t s);
     static void matmul(const fpgpu_ctx* ctx, const void* A, const void* B, void* C, size_t m, size_t k, size_t n,
+                       void* workspace, size_t workspace_bytes,
                        hipStream_t s);
     static void fill_random(const fpgpu_ctx* ctx, void* out, size_t n, uint64_t seed, hipStream_t s);
     static void pow(const fpgpu_ctx* ctx, const void* a, const uint32_t* exp32, int top_bit, void* out, size_t n,

@@ -1,0 +1,180 @@
+// Unsaturated-limb Montgomery arithmetic for the VALU-bound kernels.
+//
+// On gfx950 a carry add (v_addc_co_u32) costs the same 4 issue cycles as the multiply
+// (v_mad_u64_u32) it follows, so a saturated 32-bit-limb product
+// scanning multiplier spends half its time on carries.  Here an element is held as L
+// limbs of B < 32 bits: limb products are < 2^(2B), and 2L of them plus a carry fit a
+// 64-bit accumulator, so every column is a run of v_mad_u64_u32 with NO carry
+// instruction; a column ends with one cheap 64-bit shift.
+//
+// Bit-exactness with the reference (monty_mul, src/helpers/crypto_bigint.rs:74-107,
+// R = 2^(32*NW)): the word-by-word reduction here divides by R' = 2^(B*L) > R, so one
+// operand is loaded pre-shifted left by SH = B*L - 32*NW bits:
+//     (a * (b << SH)) / R'  ==  a * b / R   (mod p),
+// and the result is < a*b/R + p < 2p, exactly the range the reference's final
+// conditional subtraction handles; after it the canonical residue is the same number.
+#pragma once
+#include "fp_device.cuh"
+
+namespace fpgpu {
+
+template <int NW, int B>
+struct UCfg {
+    static constexpr int L = (32 * NW + B - 1) / B;  // limbs
+    static constexpr int SH = B * L - 32 * NW;       // pre-shift of one operand
+    static constexpr uint32_t MASK = (1u << B) - 1;
+    static_assert(B < 32 && SH < B, "limb width");
+    // column bound: 2L products < 2^(2B) plus a carry must stay below 2^64
+    static_assert((2 * L + 1) <= (1ull << (64 - 2 * B)), "accumulator overflow");
+};
+
+// modulus in B-bit limbs (+ its negation limb by limb, for the conditional subtract)
+template <int L>
+struct UParams {
+    uint32_t p[L];
+    uint32_t n0inv;  // -p^-1 mod 2^B
+};
+
+__device__ __forceinline__ uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t s) {
+    return __builtin_amdgcn_alignbit(hi, lo, s);  // ({hi,lo} >> s) low word, 0 <= s < 32
+}
+
+// limbs of (w << SHIFT), SHIFT < B
+template <int NW, int B, int SHIFT, int L = UCfg<NW, B>::L>
+__device__ __forceinline__ void to_limbs(uint32_t (&l)[L], const uint32_t (&w)[NW]) {
+    constexpr uint32_t M = UCfg<NW, B>::MASK;
+#pragma unroll
+    for (int i = 0; i < L; i++) {
+        const int o = i * B - SHIFT;  // bit offset of this limb in w
+        uint32_t v;
+        if (o < 0) {
+            v = w[0] << (-o);
+        } else {
+            const int j = o >> 5, s = o & 31;
+            const uint32_t lo = j < NW ? w[j] : 0u;
+            const uint32_t hi = j + 1 < NW ? w[j + 1] : 0u;
+            v = s ? alignbit(hi, lo, s) : lo;
+        }
+        l[i] = v & M;
+    }
+}
+
+// words of the value held in normalised limbs (every limb < 2^B); the value must be < 2^(32*NW)
+template <int NW, int B, int L = UCfg<NW, B>::L>
+__device__ __forceinline__ void from_limbs(uint32_t (&w)[NW], const uint32_t (&l)[L]) {
+#pragma unroll
+    for (int j = 0; j < NW; j++) {
+        const int i0 = (32 * j) / B, s = 32 * j - i0 * B;  // word j starts s bits into limb i0
+        uint32_t v = l[i0] >> s;
+        if (i0 + 1 < L) v |= l[i0 + 1] << (B - s);
+        if (2 * B - s < 32 && i0 + 2 < L) v |= l[i0 + 2] << (2 * B - s);
+        w[j] = v;
+    }
+}
+
+#include "fp_mad_groups.inc"
+constexpr int kMadGroup = 13;
+
+// acc += sum_{i<A} x[i]*y[i] + sum_{i<S} p[i]*q[i], chunk C of G
+template <int A, int S, int C, int G>
+struct MadChunks {
+    static __device__ __forceinline__ void run(uint64_t& acc, const uint32_t* x, const uint32_t* y, const uint32_t* p,
+                                               const uint32_t* q) {
+        constexpr int T = A + S;
+        constexpr int SZ = (T + G - 1) / G;
+        constexpr int START = C * SZ;
+        constexpr int LEN = START + SZ <= T ? SZ : T - START;
+        if constexpr (LEN > 0) {
+            constexpr int GV = START < A ? (START + LEN <= A ? LEN : A - START) : 0;
+            constexpr int GS = LEN - GV;
+            constexpr int V0 = START < A ? START : 0;
+            constexpr int S0 = START < A ? 0 : START - A;
+            MadG<GV, GS>::run(acc, x + V0, y + V0, p + S0, q + S0);
+        }
+        if constexpr (C + 1 < G) MadChunks<A, S, C + 1, G>::run(acc, x, y, p, q);
+    }
+};
+template <int A, int S>
+__device__ __forceinline__ void mad_column(uint64_t& acc, const uint32_t* x, const uint32_t* y, const uint32_t* p,
+                                           const uint32_t* q) {
+    if constexpr (A + S > 0) MadChunks<A, S, 0, (A + S + kMadGroup - 1) / kMadGroup>::run(acc, x, y, p, q);
+}
+
+__device__ __forceinline__ void acc_shr(uint64_t& acc, int b) {
+    uint32_t lo = (uint32_t)acc, hi = (uint32_t)(acc >> 32);
+    lo = alignbit(hi, lo, b);
+    hi >>= b;
+    acc = ((uint64_t)hi << 32) | lo;
+}
+
+// Column K of the product-scanning Montgomery multiplication.
+template <int B, int L, int K>
+struct UMontCol {
+    static __device__ __forceinline__ void run(uint64_t& acc, const uint32_t (&a)[L], const uint32_t (&b)[L],
+                                               uint32_t (&u)[L], uint32_t (&r)[L], const UParams<L>& P) {
+        constexpr uint32_t M = (1u << B) - 1;
+        if constexpr (K < L) {
+            // a_0 b_K .. a_K b_0 and u_0 p_K .. u_{K-1} p_1, then u_K and u_K p_0
+            uint32_t y[K + 1], q[K + 1];
+#pragma unroll
+            for (int i = 0; i <= K; i++) { y[i] = b[K - i]; q[i] = P.p[K - i]; }
+            mad_column<K + 1, K>(acc, a, y, u, q);
+            u[K] = ((uint32_t)acc * P.n0inv) & M;
+            acc += (uint64_t)u[K] * P.p[0];
+            acc_shr(acc, B);
+        } else {
+            constexpr int C = 2 * L - 1 - K, I0 = K - L + 1;
+            uint32_t y[C], q[C];
+#pragma unroll
+            for (int i = 0; i < C; i++) { y[i] = b[L - 1 - i]; q[i] = P.p[L - 1 - i]; }
+            mad_column<C, C>(acc, a + I0, y, u + I0, q);
+            r[K - L] = (uint32_t)acc & M;
+            acc_shr(acc, B);
+        }
+        if constexpr (K + 1 < 2 * L - 1) UMontCol<B, L, K + 1>::run(acc, a, b, u, r, P);
+    }
+};
+
+// r = a * b / 2^(B*L) mod p, r < a*b/2^(B*L) + p, limbs of r normalised.
+// a, b: limbs < 2^B (b is the pre-shifted operand when a saturated-R result is wanted).
+template <int B, int L>
+__device__ __forceinline__ void umont_mul(uint32_t (&r)[L], const uint32_t (&a)[L], const uint32_t (&b)[L],
+                                          const UParams<L>& P) {
+    uint32_t u[L];
+    uint64_t acc = 0;
+    UMontCol<B, L, 0>::run(acc, a, b, u, r, P);
+    r[L - 1] = (uint32_t)acc;
+}
+
+// r -= p if r >= p (r < 2p, limbs normalised)
+template <int B, int L>
+__device__ __forceinline__ void ucond_sub(uint32_t (&r)[L], const UParams<L>& P) {
+    constexpr uint32_t M = (1u << B) - 1;
+    uint32_t d[L];
+    int32_t borrow = 0;  // 0 or -1
+#pragma unroll
+    for (int i = 0; i < L; i++) {
+        const int32_t t = (int32_t)r[i] - (int32_t)P.p[i] + borrow;
+        borrow = t >> 31;
+        d[i] = (uint32_t)t & M;
+    }
+#pragma unroll
+    for (int i = 0; i < L; i++) r[i] = borrow ? r[i] : d[i];
+}
+
+// host-or-device helper: UParams from the saturated modulus words
+template <int NW, int B, int L = UCfg<NW, B>::L>
+__host__ __device__ inline void make_uparams(UParams<L>& U, const uint32_t* m) {
+    constexpr uint32_t M = UCfg<NW, B>::MASK;
+    for (int i = 0; i < L; i++) {
+        const int o = i * B, j = o >> 5, s = o & 31;
+        uint64_t v = j < NW ? m[j] : 0u;
+        if (j + 1 < NW) v |= (uint64_t)m[j + 1] << 32;
+        U.p[i] = (uint32_t)(v >> s) & M;
+    }
+    uint32_t inv = 1;  // Newton: p^-1 mod 2^32
+    for (int i = 0; i < 5; i++) inv *= 2u - m[0] * inv;
+    U.n0inv = (0u - inv) & M;
+}
+
+}  // namespace fpgpu

@@ -308,9 +308,16 @@ int fpgpu_matvec_dev(const fpgpu_ctx* ctx, const void* A, size_t rows, size_t co
     return FPGPU_OK;
 }
 
+size_t fpgpu_matmul_workspace_bytes(const fpgpu_ctx* ctx, size_t m, size_t k, size_t n) {
+    if (!ctx) return 0;
+    const MfmaPlan pl = make_mfma_plan(ctx->n64, m, k, n);
+    return pl.usable ? pl.bytes : 0;
+}
+
 int fpgpu_matmul_dev(const fpgpu_ctx* ctx, const void* A, const void* B, void* C, size_t m, size_t k, size_t n,
-                     void* stream) {
+                     void* workspace, size_t workspace_bytes, void* stream) {
     if (!ctx) return fail(FPGPU_ERR_SHAPE, "null context");
+    if (workspace && (uintptr_t)workspace % 256) return fail(FPGPU_ERR_SHAPE, "matmul: workspace not 256-byte aligned");
     if (m == 0 || n == 0) return FPGPU_OK;
     CHECK(check_ptr(ctx, C, "C"));
     if (k != 0) {
@@ -320,7 +327,7 @@ int fpgpu_matmul_dev(const fpgpu_ctx* ctx, const void* A, const void* B, void* C
     size_t gx = (n + kMMTile - 1) / kMMTile, gy = (m + kMMTile - 1) / kMMTile;
     if (gy > 65535 || gx > ((size_t)1 << 31) - 1) return fail(FPGPU_ERR_SHAPE, "matrix too large");
     hipStream_t s = (hipStream_t)stream;
-    DISPATCH_N64(ctx->n64, Launch<N>::matmul(ctx, A, B, C, m, k, n, s));
+    DISPATCH_N64(ctx->n64, Launch<N>::matmul(ctx, A, B, C, m, k, n, workspace, workspace_bytes, s));
     HIP_TRY(hipGetLastError());
     return FPGPU_OK;
 }
@@ -507,7 +514,10 @@ int fpgpu_matmul(const fpgpu_ctx* ctx, const uint64_t* A, const uint64_t* B, uin
         HIP_TRY(hipMemcpy(dA.p, A, m * k * esz, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(dB.p, B, k * n * esz, hipMemcpyHostToDevice));
     }
-    CHECK(fpgpu_matmul_dev(ctx, dA.p, dB.p, dC.p, m, k, n, nullptr));
+    DevBuf ws;
+    const size_t ws_bytes = fpgpu_matmul_workspace_bytes(ctx, m, k, n);
+    if (ws_bytes) CHECK(ws.alloc(ws_bytes));
+    CHECK(fpgpu_matmul_dev(ctx, dA.p, dB.p, dC.p, m, k, n, ws_bytes ? ws.p : nullptr, ws_bytes, nullptr));
     HIP_TRY(hipStreamSynchronize(nullptr));
     HIP_TRY(hipMemcpy(C, dC.p, m * n * esz, hipMemcpyDeviceToHost));
     return FPGPU_OK;

@@ -222,6 +222,15 @@ class MontyField:
         check(self._lib.fpgpu_matvec_dev(self._h, self._chk_t(A), rows, cols, self._chk_t(x), self._chk_t(y), self._stream()))
         return y
 
-    def matmul_dev(self, A, B, C, m, k, n):
-        check(self._lib.fpgpu_matmul_dev(self._h, self._chk_t(A), self._chk_t(B), self._chk_t(C), m, k, n, self._stream()))
+    def matmul_workspace_bytes(self, m, k, n):
+        return int(self._lib.fpgpu_matmul_workspace_bytes(self._h, m, k, n))
+
+    def matmul_dev(self, A, B, C, m, k, n, workspace=None):
+        """`workspace`: optional uint8 device tensor of matmul_workspace_bytes(m, k, n) bytes; with it
+        single-limb fields run on the matrix cores (same results)."""
+        wp, wb = None, 0
+        if workspace is not None:
+            wp, wb = ctypes.c_void_p(workspace.data_ptr()), workspace.numel() * workspace.element_size()
+        check(self._lib.fpgpu_matmul_dev(self._h, self._chk_t(A), self._chk_t(B), self._chk_t(C), m, k, n, wp, wb,
+                                         self._stream()))
         return C

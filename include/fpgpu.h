@@ -125,9 +125,14 @@ int fpgpu_batch_inv_dev(const fpgpu_ctx *ctx, const void *x, void *out, uint8_t 
  * A is rows*cols elements row-major; x has cols, y has rows elements. */
 int fpgpu_matvec_dev(const fpgpu_ctx *ctx, const void *A, size_t rows, size_t cols, const void *x,
                      void *y, void *stream);
-/* C[i*n + j] = sum_l mul(A[i*k + l], B[l*n + j]); A is m x k, B is k x n, C is m x n. */
+/* C[i*n + j] = sum_l mul(A[i*k + l], B[l*n + j]); A is m x k, B is k x n, C is m x n.
+ * `workspace` is optional device scratch (256-byte aligned) of at least
+ * fpgpu_matmul_workspace_bytes(ctx, m, k, n) bytes; with it, single-limb fields (n64 == 1,
+ * k <= 16320) run on the matrix cores (int8 digit planes of A and B^T live there).  Without
+ * it (NULL), or where that size is 0, the VALU kernels run.  Results are identical. */
+size_t fpgpu_matmul_workspace_bytes(const fpgpu_ctx *ctx, size_t m, size_t k, size_t n);
 int fpgpu_matmul_dev(const fpgpu_ctx *ctx, const void *A, const void *B, void *C, size_t m, size_t k,
-                     size_t n, void *stream);
+                     size_t n, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- synthetic inputs -------------------------------
  * Fills `out` with n uniform elements in [0, p): word l of element i is

@@ -257,6 +257,80 @@ def test_matmul_vs_oracle(cpa, shape):
         assert np.array_equal(f.matmul(A, B, m, k, n), o.matmul(A, B, m, k, n, threads=0))
 
 
+def _dev_matmul(cpa, f, A, B, m, k, n, use_ws):
+    import torch
+    dA = torch.from_numpy(A.view(np.int64)).cuda()
+    dB = torch.from_numpy(B.view(np.int64)).cuda()
+    dC = f.alloc(m * n)
+    ws = None
+    if use_ws:
+        nb = f.matmul_workspace_bytes(m, k, n)
+        assert nb > 0
+        ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    f.matmul_dev(dA, dB, dC, m, k, n, workspace=ws)
+    torch.cuda.synchronize()
+    return dC.cpu().numpy().view(np.uint64)
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 1), (64, 64, 64), (65, 63, 130), (17, 500, 33), (200, 1000, 70), (3, 16320, 5)])
+def test_matmul_matrix_core_path_vs_oracle(cpa, shape):
+    """Single-limb mat-mul through the int8 matrix-core kernel (workspace given) == oracle == VALU kernel,
+    on uniform elements and on the values that make the largest signed digits."""
+    m, k, n = shape
+    rnd = random.Random(m * 1000 + n)
+    for name in ("goldilocks", "p64_ref_tests"):
+        g = load_golden(name)
+        p = h2i(g["modulus"])
+        f, o = field_of(cpa, g), oracle_of(g)
+        edge = [0, 1, p - 1, p - 2, 0x7F7F7F7F7F7F7F7F % p, 0x7F7F7F7F7F7F7F80 % p, (p + 0x7F7F7F7F7F7F7F7F) % p,
+                (p - 0x8080808080808080) % p, 0x8080808080808080 % p, p >> 1, (p >> 1) + 1]
+        for mode in ("uniform", "edge"):
+            if mode == "uniform":
+                A = ints_to_array(synth_elements(p, 1, m * k, 71), 1)
+                B = ints_to_array(synth_elements(p, 1, k * n, 72), 1)
+            else:
+                A = ints_to_array([rnd.choice(edge) for _ in range(m * k)], 1)
+                B = ints_to_array([rnd.choice(edge) for _ in range(k * n)], 1)
+            want = o.matmul(A, B, m, k, n, threads=0)
+            assert np.array_equal(_dev_matmul(cpa, f, A, B, m, k, n, True).reshape(want.shape), want), (name, mode, "mfma")
+            assert np.array_equal(_dev_matmul(cpa, f, A, B, m, k, n, False).reshape(want.shape), want), (name, mode, "valu")
+
+
+def test_matmul_matrix_core_extreme_digits(cpa):
+    """K = 16320 with every digit product at its extreme (+127*127 and -128*-128... the int32 bound)."""
+    g = load_golden("goldilocks")
+    p = h2i(g["modulus"])
+    f, o = field_of(cpa, g), oracle_of(g)
+    m, k, n = 2, 16320, 3
+    for va, vb in [(0x7F7F7F7F7F7F7F7F, 0x7F7F7F7F7F7F7F7F), (0x7F7F7F7F7F7F7F80, 0x7F7F7F7F7F7F7F80),
+                   (0x7F7F7F7F7F7F7F7F, 0x7F7F7F7F7F7F7F80)]:
+        A = ints_to_array([va % p] * (m * k), 1)
+        B = ints_to_array([vb % p] * (k * n), 1)
+        want = o.matmul(A, B, m, k, n, threads=0)
+        assert np.array_equal(_dev_matmul(cpa, f, A, B, m, k, n, True).reshape(want.shape), want)
+
+
+def test_matmul_matrix_core_falls_back_on_undigitisable_inputs(cpa):
+    """Non-canonical inputs x >= p with x - p beyond eight signed digits: the digitiser flags them and the
+    VALU kernel (which takes any a < R, as monty_mul does) produces the result."""
+    p = 2**61 - 1
+    f = cpa.MontyField(p, 1)
+    from oracle.fp_oracle import Oracle
+    o = Oracle(p, 1)
+    m, k, n = 5, 70, 9
+    rnd = random.Random(3)
+    A = ints_to_array([rnd.randrange(p) for _ in range(m * k)], 1)
+    B = ints_to_array([rnd.randrange(p) for _ in range(k * n)], 1)
+    A[7, 0] = np.uint64(2**64 - 1)
+    want = _dev_matmul(cpa, f, A, B, m, k, n, False)
+    assert np.array_equal(_dev_matmul(cpa, f, A, B, m, k, n, True), want)
+    # the same numbers reduced first give the same residues through the oracle
+    A2 = A.copy()
+    A2[7, 0] = np.uint64((2**64 - 1) % p)
+    got2 = _dev_matmul(cpa, f, A2, B, m, k, n, True)
+    assert np.array_equal(got2.reshape(-1), o.matmul(A2, B, m, k, n, threads=0).reshape(-1))
+
+
 @pytest.mark.parametrize("name", ["bn254_fr", "goldilocks", "bls12_381_fq", "odd_composite_128"])
 def test_pow_vs_oracle(cpa, name):
     # SURVEY.md 8f N1: batched pow, one exponent per batch; oracle = the reference's 4-bit-window AMM ladder
