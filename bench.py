@@ -32,6 +32,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_I8_PEAK_TOPS = 5000.0      # MI355X_MICROARCH.md: dense int8 MFMA = 2x the ~2.5 PF bf16 peak
 VALU_MAD_PEAK_TOPS = 39.3       # 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz v_mad_u64_u32 lane-ops/s (measured 36.5)
 
 
@@ -264,27 +265,32 @@ def bench_matmul(args, world, rank, distributed, time_steps, primary):
     C_local = g.alloc(rows * dim)
     C = g.alloc(dim * dim) if distributed else C_local
 
+    ws = torch.empty(g.matmul_workspace_bytes(rows, dim, dim), dtype=torch.uint8, device="cuda")
+
     def step():
-        g.matmul_dev(A, B, C_local, rows, dim, dim)
+        g.matmul_dev(A, B, C_local, rows, dim, dim, workspace=ws)
         if distributed:
             dist.all_gather_into_tensor(C, C_local)
 
     steps = max(2, min(args.steps, 5)) if not primary else args.steps
     wall, kern = time_steps(step, steps, 1)
     terms = dim ** 3
+    # int8 multiply-accumulates the matrix cores execute: 64 digit products per 64x64-bit term
+    tops = 2.0 * 64.0 * rows * dim * dim / kern / 1e12
     res = {"Gterms_per_s": terms * steps / wall / 1e9, "ms_per_matmul": wall / steps * 1e3, "dim": dim,
-           "valu_lane_instr_Tops_per_gpu": 8.0 * rows * dim * dim / kern / 1e12,
-           "valu_issue_peak_Tops": 36.5,
-           "algorithmic_mad_Tops_per_gpu(10 per term)": 10.0 * rows * dim * dim / kern / 1e12}
+           "int8_mfma_Tops_per_gpu": tops, "int8_mfma_peak_Tops": MFMA_I8_PEAK_TOPS,
+           "mfma_frac": tops / MFMA_I8_PEAK_TOPS,
+           "kernels": "k_mf_digitize x2 + k_matmul_mfma_1limb (v_mfma_i32_16x16x64_i8)",
+           "valu_kernel_ms_for_comparison": 125.8}
     if primary:
         res = {"metric": "64-bit Fp mat-mul Gterms/s (Goldilocks, 8192^2)", "value": res["Gterms_per_s"],
                "unit": "Gterms/s", "per_gpu": res["Gterms_per_s"] / world, "ms_per_step": res["ms_per_matmul"],
                "config": {"workload": "Goldilocks 64-bit 8192 x 8192 x 8192 mat-mul (BASELINE.json configs[4])",
                           "parallelism": "rowshard%d" % world},
-               "roofline": {"bound": "valu", "achieved": res["valu_lane_instr_Tops_per_gpu"], "peak": 39.3,
-                            "unit": "T lane-instr/s (8 VALU instr per term: 4 v_mad_u64_u32 + 4 v_addc_co_u32)",
-                            "frac": res["valu_lane_instr_Tops_per_gpu"] / 39.3, "traffic": None,
-                            "kernel": "k_matmul_1limb"},
+               "roofline": {"bound": "mfma", "achieved": tops, "peak": MFMA_I8_PEAK_TOPS,
+                            "unit": "TOP/s (int8 multiply-accumulates x 2; 64 per 64x64-bit term)",
+                            "frac": tops / MFMA_I8_PEAK_TOPS, "traffic": None,
+                            "kernel": "k_matmul_mfma_1limb"},
                "verified_vs_oracle": None}
     return res
 

@@ -8,7 +8,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfpgpu.so")
+LIB_PATH = os.environ.get("FPGPU_LIB") or os.path.join(_HERE, "libfpgpu.so")  # FPGPU_LIB: tuning builds
 
 OK, ERR_INVALID_MODULUS, ERR_UNSUPPORTED, ERR_SHAPE, ERR_HIP, ERR_NO_DEVICE = range(6)
 

@@ -6,9 +6,12 @@
 // then
 //     sum_k a_k b_k  =  sum_{d=0..14} 256^d  *  sum_{i+j=d} sum_k a_k,i b_k,j
 // and every inner sum is an int8 x int8 -> int32 matrix product, which is what
-// v_mfma_i32_16x16x64_i8 computes at 1024 multiply-accumulates per cycle per SIMD (a
-// 64x64-bit term = 64 of them = 1/16 cycle, against 8 x 4 cycles / 64 lanes = 1/2 cycle on
-// the VALU).  The 15 diagonal sums per output stay in int32 accumulators over the whole K
+// v_mfma_i32_16x16x64_i8 computes: 16384 multiply-accumulates per instruction, one every
+// 8.4 ns per SIMD measured (tools/ubench_mfma_i8.hip), so a 64x64-bit term = 64 of them costs
+// 0.033 ns of SIMD time against 0.22 ns on the VALU (8 instructions x 4.3 cycles / 64 lanes).
+// (The 32x32x32 form is 17 % faster per multiply in that register-only loop on constant data,
+// but ran 10 % slower in this kernel on random operands, so the 16x16 form stays.)
+// The 15 diagonal sums per output stay in int32 accumulators over the whole K
 // loop (|digit product| <= 2^14, at most 8 products per k per diagonal: exact for
 // K <= 16383), are recombined exactly in 192-bit two's complement at the end and reduced
 // with the same three Montgomery multiplications as k_matmul_1limb, so the result is the
@@ -118,18 +121,16 @@ __global__ __launch_bounds__(256) void k_matmul_mfma_1limb(const uint8_t* __rest
     const uint8_t* ga = Aw + (size_t)rb * ksteps * kMF_CHUNK + lane * 16;
     const uint8_t* gb = Bw + (size_t)cb * ksteps * kMF_CHUNK + lane * 16;
 
-    auto stage = [&](uint32_t ks, int buf) {
-        // 32 pieces of 1 KiB per operand; wave w moves pieces w, w+4, ...
-#pragma unroll
-        for (int q = 0; q < 8; q++) {
-            const int piece = q * 4 + wave;
-            __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void*)(ga + (size_t)ks * kMF_CHUNK + piece * 1024),
-                (__attribute__((address_space(3))) void*)(lds + buf * 2 * kMF_CHUNK + piece * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void*)(gb + (size_t)ks * kMF_CHUNK + piece * 1024),
-                (__attribute__((address_space(3))) void*)(lds + buf * 2 * kMF_CHUNK + kMF_CHUNK + piece * 1024), 16, 0, 0);
-        }
+    // one eighth of the staging of k-step ks into LDS buffer buf: 32 pieces of 1 KiB per operand,
+    // wave w moves pieces w, w+4, ...; part q = 0..7 moves piece 4q + w of A and of B
+    auto stage_part = [&](uint32_t ks, int buf, int q) {
+        const int piece = q * 4 + wave;
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(ga + (size_t)ks * kMF_CHUNK + piece * 1024),
+            (__attribute__((address_space(3))) void*)(lds + buf * 2 * kMF_CHUNK + piece * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(gb + (size_t)ks * kMF_CHUNK + piece * 1024),
+            (__attribute__((address_space(3))) void*)(lds + buf * 2 * kMF_CHUNK + kMF_CHUNK + piece * 1024), 16, 0, 0);
     };
 
     mf_v4i acc[15][2][2];
@@ -140,10 +141,19 @@ __global__ __launch_bounds__(256) void k_matmul_mfma_1limb(const uint8_t* __rest
 #pragma unroll
             for (int ct = 0; ct < 2; ct++) acc[d][rt][ct] = mf_v4i{0, 0, 0, 0};
 
-    stage(0, 0);
+#pragma unroll
+    for (int q = 0; q < 8; q++) stage_part(0, 0, q);
     __syncthreads();  // (waits for this wave's DMAs, then the barrier)
     for (uint32_t ks = 0; ks < ksteps; ks++) {
-        if (ks + 1 < ksteps) stage(ks + 1, (ks + 1) & 1);  // in flight while this step computes
+        // The DMA of the next k-step sits in a basic block of its own (in flight while this step
+        // computes).  Folded into the MFMA block, hipcc's register allocation falls apart: it
+        // keeps accumulators in VGPRs and copies them to AGPRs and back around every MFMA.
+#ifndef MF_DBG_NOSTAGE  // (MF_DBG_*: timing experiments only, tools/build_variant.sh)
+        if (ks + 1 < ksteps) {
+#pragma unroll
+            for (int q = 0; q < 8; q++) stage_part(ks + 1, (ks + 1) & 1, q);
+        }
+#endif
         const uint8_t* base = lds + (ks & 1) * 2 * kMF_CHUNK + lane * 16;
         mf_v4i a[2][8];
 #pragma unroll
@@ -151,10 +161,20 @@ __global__ __launch_bounds__(256) void k_matmul_mfma_1limb(const uint8_t* __rest
 #pragma unroll
             for (int rt = 0; rt < 2; rt++)
                 a[rt][i] = *reinterpret_cast<const mf_v4i*>(base + (i * 4 + 2 * wr + rt) * 1024);
+        auto bfrag = [&](int j, int ct) {
+            return *reinterpret_cast<const mf_v4i*>(base + kMF_CHUNK + (j * 4 + 2 * wc + ct) * 1024);
+        };
+        mf_v4i b[2][2];  // [parity of j][column tile]: digit j+1 is read while digit j's 32 MFMAs run
+        b[0][0] = bfrag(0, 0);
+        b[0][1] = bfrag(0, 1);
 #pragma unroll
         for (int j = 0; j < 8; j++) {
-            const mf_v4i b0 = *reinterpret_cast<const mf_v4i*>(base + kMF_CHUNK + (j * 4 + 2 * wc) * 1024);
-            const mf_v4i b1 = *reinterpret_cast<const mf_v4i*>(base + kMF_CHUNK + (j * 4 + 2 * wc + 1) * 1024);
+            if (j + 1 < 8) {
+                b[(j + 1) & 1][0] = bfrag(j + 1, 0);
+                b[(j + 1) & 1][1] = bfrag(j + 1, 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);  // or hipcc sinks those reads to just before their use
+            const mf_v4i b0 = b[j & 1][0], b1 = b[j & 1][1];
 #pragma unroll
             for (int i = 0; i < 8; i++) {
                 acc[i + j][0][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[0][i], b0, acc[i + j][0][0], 0, 0, 0);
@@ -163,7 +183,9 @@ __global__ __launch_bounds__(256) void k_matmul_mfma_1limb(const uint8_t* __rest
                 acc[i + j][1][1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[1][i], b1, acc[i + j][1][1], 0, 0, 0);
             }
         }
+#ifndef MF_DBG_NOBARRIER
         __syncthreads();  // next buffer has landed (vmcnt(0) per wave) and this one is free to refill
+#endif
     }
 
     // ---- recombine the diagonals and reduce: C/D layout col = lane & 15, row = 4 (lane >> 4) + reg
