@@ -307,8 +307,10 @@ def bench_matvec(args, f, world, rank, distributed, time_steps, primary):
     y_local = f.alloc(rows)
     y = f.alloc(dim) if distributed else y_local
 
+    ws = torch.empty(f.matvec_workspace_bytes(rows, dim), dtype=torch.uint8, device="cuda")
+
     def step():
-        f.matvec_dev(A, rows, dim, x, y_local)
+        f.matvec_dev(A, rows, dim, x, y_local, workspace=ws)
         if distributed:
             dist.all_gather_into_tensor(y, y_local)
 
@@ -326,7 +328,8 @@ def bench_matvec(args, f, world, rank, distributed, time_steps, primary):
                                       "(BASELINE.json configs[3])" % (args.matvec_log2, args.matvec_log2),
                           "parallelism": "rowshard%d+allgather" % world},
                "roofline": {"bound": "hbm", "achieved": res["hbm_GBps_per_gpu"], "peak": HBM_PEAK_GBPS,
-                            "unit": "GB/s", "frac": res["hbm_frac"], "traffic": None, "kernel": "k_matvec<8>"},
+                            "unit": "GB/s", "frac": res["hbm_frac"], "traffic": None,
+                            "kernel": "k_matvec_mfma<8,4> (+ k_mv_expand, k_mv_finish)"},
                "verified_vs_oracle": None}
     return res
 

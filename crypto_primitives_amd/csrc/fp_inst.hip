@@ -6,6 +6,7 @@
 #if FPGPU_N == 2
 #include "fp_matmul_mfma.cuh"
 #endif
+#include "fp_matvec_mfma.cuh"
 
 #ifndef FPGPU_N
 #error "compile with -DFPGPU_N=<number of 32-bit limbs>"
@@ -105,7 +106,36 @@ void Launch<N>::batch_inv(const fpgpu_ctx* ctx, const void* x, void* out, uint8_
 
 template <int N>
 void Launch<N>::matvec(const fpgpu_ctx* ctx, const void* A, size_t rows, size_t cols, const void* x, void* y,
-                       hipStream_t s) {
+                       void* workspace, size_t workspace_bytes, hipStream_t s) {
+    // Matrix-core path (fp_matvec_mfma.cuh) when the caller brings the workspace; FPGPU_MATVEC_MFMA=0
+    // forces the VALU kernel (A/B checks and timing).  The VALU kernel still runs after it, gated by
+    // the digitiser's flag (x not representable in signed digits).
+    const uint32_t* gate = nullptr;
+    {
+        MvPlan pl = make_mv_plan(ctx->n64, rows, cols);
+        const char* e = getenv("FPGPU_MATVEC_MFMA");
+        const char* ksp = getenv("FPGPU_MATVEC_KSPLIT");  // tuning / test hook: column parts per row block
+        if (ksp && atoi(ksp) > 0 && pl.usable) pl.ksplit = (uint32_t)atoi(ksp) < pl.chunks_total ? (uint32_t)atoi(ksp) : pl.chunks_total;
+        if (pl.usable && workspace && workspace_bytes >= pl.bytes && !(e && !atoi(e)) && (uintptr_t)A % 16 == 0) {
+            constexpr int NT = N / 2;
+            uint8_t* ws = (uint8_t*)workspace;
+            uint32_t* flag = (uint32_t*)ws;
+            unsigned long long* colsum = (unsigned long long*)(ws + pl.colsum_off);
+            unsigned long long* Dbuf = (unsigned long long*)(ws + pl.d_off);
+            uint8_t* Bw = ws + pl.b_off;
+            (void)hipMemsetAsync(ws, 0, pl.b_off, s);
+            const size_t ksteps = (size_t)pl.chunks_total * 8;
+            const unsigned eg = (unsigned)(ksteps < 512 ? ksteps : 512);
+            hipLaunchKernelGGL((k_mv_expand<N, NT>), dim3(eg), dim3(NT * 64), 0, s, (const uint32_t*)x, cols, ksteps, Bw,
+                               colsum, flag, make_params<N>(ctx));
+            hipLaunchKernelGGL((k_matvec_mfma<N, NT>), dim3(pl.rowblocks * pl.ksplit), dim3(kMV_WAVES * 64), 0, s,
+                               (const uint8_t*)A, rows, cols * (size_t)(4 * N), Bw, pl.chunks_total, pl.ksplit, Dbuf,
+                               (const uint32_t*)flag);
+            hipLaunchKernelGGL((k_mv_finish<N, NT>), dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, Dbuf, colsum,
+                               (uint32_t*)y, rows, (const uint32_t*)flag, make_params<N>(ctx));
+            gate = flag;
+        }
+    }
     // Terms per product-scanning pass: T products may be summed before the wide add only
     // if T*p <= R, i.e. the modulus leaves log2(T) zero bits at the top of its container.
     // Measured on MI355X (2^15 x 2^15, BN254): T = 1 (66 VGPRs, 7 waves/SIMD) 6.96 ms,
@@ -124,11 +154,11 @@ void Launch<N>::matvec(const fpgpu_ctx* ctx, const void* A, size_t rows, size_t 
     const uint32_t* xp = (const uint32_t*)x;
     uint32_t* yp = (uint32_t*)y;
     if (T >= 4)
-        hipLaunchKernelGGL((k_matvec<N, 4>), dim3(grid), dim3(kBlock), 0, s, Ap, xp, yp, rows, cols, make_params<N>(ctx));
+        hipLaunchKernelGGL((k_matvec<N, 4>), dim3(grid), dim3(kBlock), 0, s, Ap, xp, yp, rows, cols, gate, make_params<N>(ctx));
     else if (T >= 2)
-        hipLaunchKernelGGL((k_matvec<N, 2>), dim3(grid), dim3(kBlock), 0, s, Ap, xp, yp, rows, cols, make_params<N>(ctx));
+        hipLaunchKernelGGL((k_matvec<N, 2>), dim3(grid), dim3(kBlock), 0, s, Ap, xp, yp, rows, cols, gate, make_params<N>(ctx));
     else
-        hipLaunchKernelGGL((k_matvec<N, 1>), dim3(grid), dim3(kBlock), 0, s, Ap, xp, yp, rows, cols, make_params<N>(ctx));
+        hipLaunchKernelGGL((k_matvec<N, 1>), dim3(grid), dim3(kBlock), 0, s, Ap, xp, yp, rows, cols, gate, make_params<N>(ctx));
 }
 
 template <int N>

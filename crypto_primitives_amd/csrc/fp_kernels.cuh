@@ -422,8 +422,10 @@ __device__ __forceinline__ void wave_reduce_add(uint32_t (&acc)[N], const FpPara
 template <int N, int T>
 __global__ __launch_bounds__(kBlock) void k_matvec(const uint32_t* __restrict__ A, const uint32_t* __restrict__ x,
                                                    uint32_t* __restrict__ y, size_t rows, size_t cols,
-                                                   const FpParams<N> P) {
+                                                   const uint32_t* __restrict__ run_if_set, const FpParams<N> P) {
     __shared__ uint32_t part[kBlock / 64][N];
+    // as the fallback of k_matvec_mfma this runs only when the digitiser raised its flag
+    if (run_if_set && *run_if_set == 0) return;
     for (size_t row = blockIdx.x; row < rows; row += gridDim.x) {
         const uint32_t* __restrict__ Arow = A + row * cols * N;
         uint32_t S[2 * N];

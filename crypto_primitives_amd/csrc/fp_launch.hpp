@@ -42,6 +42,38 @@ struct InvPlan {
     size_t bytes = 0;
 };
 InvPlan make_inv_plan(uint32_t n64, size_t n);
+// Workspace of the matrix-core mat-vec (fp_matvec_mfma.cuh): flag, column sums, the 64-bit
+// diagonal sums D[rows][16 NT], then the Toeplitz expansion of x in 64-byte k-steps x NT KiB.
+#ifndef FPGPU_MV_WAVES
+#define FPGPU_MV_WAVES 8
+#endif
+constexpr int kMV_WAVES = FPGPU_MV_WAVES;  // waves per workgroup of k_matvec_mfma: 16 rows each
+struct MvPlan {
+    bool usable;
+    uint32_t nt, rowblocks, ksplit, chunks_total;
+    size_t colsum_off, d_off, b_off, bytes;
+};
+inline MvPlan make_mv_plan(uint32_t n64, size_t rows, size_t cols) {
+    MvPlan pl{};
+    const size_t eb = 8 * (size_t)n64;
+    // the finishing kernel's 64-bit diagonal groups hold cols * EB <= 2^23 exactly
+    // and rows must be whole 16-byte pieces (odd n64 with odd cols is left to the VALU kernel)
+    pl.usable = rows > 0 && cols > 0 && cols * eb <= ((size_t)1 << 23) && rows <= ((size_t)1 << 24) &&
+                (cols * eb) % 16 == 0 && cols * eb >= 64;
+    if (!pl.usable) return pl;
+    pl.nt = n64;  // ceil((2 EB - 1) / 16)
+    pl.rowblocks = (uint32_t)((rows + kMV_WAVES * 16 - 1) / (kMV_WAVES * 16));
+    const size_t ksteps = (cols * eb + 63) / 64;
+    pl.chunks_total = (uint32_t)((ksteps + 7) / 8);
+    uint32_t ks = (256 + pl.rowblocks - 1) / pl.rowblocks;  // at least one workgroup per CU; columns split when rows are few
+    if (ks > pl.chunks_total) ks = pl.chunks_total;
+    pl.ksplit = ks < 1 ? 1 : ks;
+    pl.colsum_off = 256;
+    pl.d_off = pl.colsum_off + ((16 * pl.nt * 8 + 255) / 256) * 256;
+    pl.b_off = pl.d_off + (((size_t)pl.rowblocks * (kMV_WAVES * 16) * 16 * pl.nt * 8 + 1023) / 1024) * 1024;
+    pl.bytes = pl.b_off + (size_t)pl.chunks_total * 8 * pl.nt * 1024;
+    return pl;
+}
 // Workspace of the matrix-core mat-mul (fp_matmul_mfma.cuh): a flag word, then the int8 digit
 // planes of A and of B^T in 64-row blocks x 64-deep k-steps x 32 KiB.
 struct MfmaPlan {
@@ -73,6 +105,7 @@ struct Launch {
     static void batch_inv(const fpgpu_ctx* ctx, const void* x, void* out, uint8_t* flags, size_t n, char* ws,
                           hipStream_t s);
     static void matvec(const fpgpu_ctx* ctx, const void* A, size_t rows, size_t cols, const void* x, void* y,
+                       void* workspace, size_t workspace_bytes,
                        hipStream_t s);
     static void matmul(const fpgpu_ctx* ctx, const void* A, const void* B, void* C, size_t m, size_t k, size_t n,
                        void* workspace, size_t workspace_bytes,

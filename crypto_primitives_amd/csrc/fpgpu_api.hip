@@ -292,8 +292,15 @@ int fpgpu_batch_inv_dev(const fpgpu_ctx* ctx, const void* x, void* out, uint8_t*
     return FPGPU_OK;
 }
 
+size_t fpgpu_matvec_workspace_bytes(const fpgpu_ctx* ctx, size_t rows, size_t cols) {
+    if (!ctx) return 0;
+    const MvPlan pl = make_mv_plan(ctx->n64, rows, cols);
+    return pl.usable ? pl.bytes : 0;
+}
+
 int fpgpu_matvec_dev(const fpgpu_ctx* ctx, const void* A, size_t rows, size_t cols, const void* x, void* y,
-                     void* stream) {
+                     void* workspace, size_t workspace_bytes, void* stream) {
+    if (workspace && (uintptr_t)workspace % 256) return fail(FPGPU_ERR_SHAPE, "matvec: workspace not 256-byte aligned");
     if (!ctx) return fail(FPGPU_ERR_SHAPE, "null context");
     if (rows == 0) return FPGPU_OK;
     if (cols != 0 && rows > ((size_t)1 << 40) / cols) return fail(FPGPU_ERR_SHAPE, "matrix too large");
@@ -303,7 +310,7 @@ int fpgpu_matvec_dev(const fpgpu_ctx* ctx, const void* A, size_t rows, size_t co
         CHECK(check_ptr(ctx, x, "x"));
     }
     hipStream_t s = (hipStream_t)stream;
-    DISPATCH_N64(ctx->n64, Launch<N>::matvec(ctx, A, rows, cols, x, y, s));
+    DISPATCH_N64(ctx->n64, Launch<N>::matvec(ctx, A, rows, cols, x, y, workspace, workspace_bytes, s));
     HIP_TRY(hipGetLastError());
     return FPGPU_OK;
 }
@@ -493,7 +500,10 @@ int fpgpu_matvec(const fpgpu_ctx* ctx, const uint64_t* A, size_t rows, size_t co
         HIP_TRY(hipMemcpy(dA.p, A, rows * cols * esz, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(dx.p, x, cols * esz, hipMemcpyHostToDevice));
     }
-    CHECK(fpgpu_matvec_dev(ctx, dA.p, rows, cols, dx.p, dy.p, nullptr));
+    DevBuf ws;
+    const size_t ws_bytes = fpgpu_matvec_workspace_bytes(ctx, rows, cols);
+    if (ws_bytes) CHECK(ws.alloc(ws_bytes));
+    CHECK(fpgpu_matvec_dev(ctx, dA.p, rows, cols, dx.p, dy.p, ws_bytes ? ws.p : nullptr, ws_bytes, nullptr));
     HIP_TRY(hipStreamSynchronize(nullptr));
     HIP_TRY(hipMemcpy(y, dy.p, rows * esz, hipMemcpyDeviceToHost));
     return FPGPU_OK;

@@ -218,8 +218,17 @@ class MontyField:
                                             self._stream()))
         return out
 
-    def matvec_dev(self, A, rows, cols, x, y):
-        check(self._lib.fpgpu_matvec_dev(self._h, self._chk_t(A), rows, cols, self._chk_t(x), self._chk_t(y), self._stream()))
+    def matvec_workspace_bytes(self, rows, cols):
+        return int(self._lib.fpgpu_matvec_workspace_bytes(self._h, rows, cols))
+
+    def matvec_dev(self, A, rows, cols, x, y, workspace=None):
+        """`workspace`: optional uint8 device tensor of matvec_workspace_bytes(rows, cols) bytes; with it
+        the products run on the matrix cores (same results)."""
+        wp, wb = None, 0
+        if workspace is not None:
+            wp, wb = ctypes.c_void_p(workspace.data_ptr()), workspace.numel() * workspace.element_size()
+        check(self._lib.fpgpu_matvec_dev(self._h, self._chk_t(A), rows, cols, self._chk_t(x), self._chk_t(y), wp, wb,
+                                         self._stream()))
         return y
 
     def matmul_workspace_bytes(self, m, k, n):

@@ -122,9 +122,14 @@ int fpgpu_batch_inv_dev(const fpgpu_ctx *ctx, const void *x, void *out, uint8_t 
 /* ---- dense matrix products over DenseRowMatrix<T> (src/matrix.rs:135-164) --
  * y[i] = sum_j mul(A[i*cols + j], x[j]): the SemiringConfig::sum_refs fold
  * (src/semiring.rs:213-226) of monty_mul over DenseRowMatrix::as_rows().
- * A is rows*cols elements row-major; x has cols, y has rows elements. */
+ * A is rows*cols elements row-major; x has cols, y has rows elements.
+ * `workspace` is optional device scratch (256-byte aligned) of at least
+ * fpgpu_matvec_workspace_bytes(ctx, rows, cols) bytes; with it the products run on the matrix
+ * cores (A streamed once, as it lies) and the call is HBM-bound; without it (NULL), or where
+ * that size is 0, the VALU kernel runs.  Results are identical. */
+size_t fpgpu_matvec_workspace_bytes(const fpgpu_ctx *ctx, size_t rows, size_t cols);
 int fpgpu_matvec_dev(const fpgpu_ctx *ctx, const void *A, size_t rows, size_t cols, const void *x,
-                     void *y, void *stream);
+                     void *y, void *workspace, size_t workspace_bytes, void *stream);
 /* C[i*n + j] = sum_l mul(A[i*k + l], B[l*n + j]); A is m x k, B is k x n, C is m x n.
  * `workspace` is optional device scratch (256-byte aligned) of at least
  * fpgpu_matmul_workspace_bytes(ctx, m, k, n) bytes; with it, single-limb fields (n64 == 1,

@@ -257,6 +257,83 @@ def test_matmul_vs_oracle(cpa, shape):
         assert np.array_equal(f.matmul(A, B, m, k, n), o.matmul(A, B, m, k, n, threads=0))
 
 
+def _dev_matvec(cpa, f, A, rows, cols, x, use_ws):
+    import torch
+    dA = torch.from_numpy(A.view(np.int64)).cuda()
+    dx = torch.from_numpy(x.view(np.int64)).cuda()
+    dy = f.alloc(rows)
+    ws = None
+    if use_ws:
+        nb = f.matvec_workspace_bytes(rows, cols)   # 0: shape left to the VALU kernel (tiny or ragged rows)
+        assert nb > 0 or cols * f.n64 * 8 < 64 or (cols * f.n64 * 8) % 16
+        ws = torch.empty(max(nb, 256), dtype=torch.uint8, device="cuda")
+    f.matvec_dev(dA, rows, cols, dx, dy, workspace=ws)
+    torch.cuda.synchronize()
+    return dy.cpu().numpy().view(np.uint64)
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (3, 1000), (16, 2), (130, 257), (257, 513), (129, 31), (40, 4099)])
+def test_matvec_matrix_core_path_vs_oracle(cpa, shape):
+    """Mat-vec through the int8 matrix-core kernels (workspace given) == oracle == VALU kernel, on
+    uniform elements and on byte patterns at the extremes of the signed digits."""
+    rows, cols = shape
+    rnd = random.Random(rows * 7 + cols)
+    for name in ("bn254_fr", "goldilocks", "bls12_381_fq", "bench_120bit"):
+        g = load_golden(name)
+        p, n64 = h2i(g["modulus"]), g["n64"]
+        f, o = field_of(cpa, g), oracle_of(g)
+        nb = 8 * n64
+        pats = [0, 1, p - 1, p - 2, p >> 1, (p >> 1) + 1] + [int.from_bytes(bytes([b]) * nb, "little") % p
+                                                              for b in (0x7F, 0x80, 0xFF, 0x81, 0x01)]
+        pats += [(p + int.from_bytes(bytes([0x7F]) * nb, "little") + 1) % p, (p - int.from_bytes(bytes([0x80]) * nb, "little")) % p]
+        for mode in ("uniform", "edge"):
+            if mode == "uniform":
+                A = ints_to_array(synth_elements(p, n64, rows * cols, 81), n64)
+                x = ints_to_array(synth_elements(p, n64, cols, 82), n64)
+            else:
+                A = ints_to_array([rnd.choice(pats) for _ in range(rows * cols)], n64)
+                x = ints_to_array([rnd.choice(pats) for _ in range(cols)], n64)
+            want = o.matvec(A, rows, cols, x, threads=0)
+            got = _dev_matvec(cpa, f, A, rows, cols, x, True)
+            assert np.array_equal(got.reshape(want.shape), want), (name, mode, "mfma")
+            got = _dev_matvec(cpa, f, A, rows, cols, x, False)
+            assert np.array_equal(got.reshape(want.shape), want), (name, mode, "valu")
+
+
+def test_matvec_matrix_core_int32_flush_and_column_split(cpa, monkeypatch):
+    """One column part per row block (forced) so that the int32 tiles are flushed inside the loop
+    (every 255 chunks = 4080 elements), then the default split over many workgroups; extreme bytes."""
+    g = load_golden("bn254_fr")
+    p, n64 = h2i(g["modulus"]), g["n64"]
+    f, o = field_of(cpa, g), oracle_of(g)
+    rows, cols = 20, 9001
+    for va, vx in [(int.from_bytes(b"\xff" * 31 + b"\x2f", "little") % p, int.from_bytes(b"\x80" * 32, "little") % p),
+                   (int.from_bytes(b"\x00" * 32, "little"), p - 1), (p - 1, int.from_bytes(b"\x7f" * 32, "little") % p)]:
+        A = ints_to_array([va] * (rows * cols), n64)
+        x = ints_to_array([vx] * cols, n64)
+        want = o.matvec(A, rows, cols, x, threads=0)
+        for ks in ("1", "3", None):
+            if ks is None:
+                monkeypatch.delenv("FPGPU_MATVEC_KSPLIT", raising=False)
+            else:
+                monkeypatch.setenv("FPGPU_MATVEC_KSPLIT", ks)
+            got = _dev_matvec(cpa, f, A, rows, cols, x, True)
+            assert np.array_equal(got.reshape(want.shape), want), (hex(va), hex(vx), ks)
+
+
+def test_matvec_matrix_core_falls_back_on_undigitisable_x(cpa):
+    """x >= p whose x - p does not fit the signed digits: flagged on the device, the VALU kernel answers."""
+    g = load_golden("bench_120bit")
+    p, n64 = h2i(g["modulus"]), g["n64"]
+    f = field_of(cpa, g)
+    rows, cols = 9, 77
+    A = ints_to_array(synth_elements(p, n64, rows * cols, 91), n64)
+    x = ints_to_array(synth_elements(p, n64, cols, 92), n64)
+    x[5, :] = np.uint64(2**64 - 1)
+    want = _dev_matvec(cpa, f, A, rows, cols, x, False)
+    assert np.array_equal(_dev_matvec(cpa, f, A, rows, cols, x, True), want)
+
+
 def _dev_matmul(cpa, f, A, B, m, k, n, use_ws):
     import torch
     dA = torch.from_numpy(A.view(np.int64)).cuda()
