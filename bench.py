@@ -328,10 +328,20 @@ def bench_matvec(args, f, world, rank, distributed, time_steps, primary):
                                       "(BASELINE.json configs[3])" % (args.matvec_log2, args.matvec_log2),
                           "parallelism": "rowshard%d+allgather" % world},
                "roofline": {"bound": "hbm", "achieved": res["hbm_GBps_per_gpu"], "peak": HBM_PEAK_GBPS,
-                            "unit": "GB/s", "frac": res["hbm_frac"], "traffic": None,
+                            "unit": "GB/s", "frac": res["hbm_frac"], "traffic": _pmc_traffic("matvec", "rows", rows),
                             "kernel": "k_matvec_mfma<8,4> (+ k_mv_expand, k_mv_finish)"},
                "verified_vs_oracle": None}
     return res
+
+
+def _pmc_traffic(workload, key, value):
+    """HBM bytes per launch from the PMC passes kept under profiles/ (bench.py cannot profile itself)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic_%s.json" % workload)) as fh:
+            pmc = json.load(fh)
+        return pmc["traffic_bytes_per_launch"] if pmc.get(key) == value else None
+    except (OSError, ValueError, KeyError):
+        return None
 
 
 def cpu_baseline():
