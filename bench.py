@@ -371,7 +371,17 @@ def cpu_baseline():
     t1 = time.perf_counter()
     o.mul(a[: n // 8], b[: n // 8], threads=1)
     single = (n // 8) / (time.perf_counter() - t1) / 1e9
+    # the reference's own bench shape (benches/field_ops_bench_common.rs): 10000 operations on one element,
+    # four seeds, eight groups, single core; on its 120-bit bench modulus and on BN254 Fr
+    from oracle.fp_oracle import bench_reference_shape
+    p120 = 0x00000000000000000000000000000000860995AE68FC80E1B1BD1E39D54B33  # benches/const_monty_field_benches.rs:9-13
+    ref_shape = {}
+    for label, mod in (("bench_120bit_prime", p120), ("bn254_fr", cpa.BN254_FR)):
+        per_seed = bench_reference_shape(mod, 4, 10000)
+        groups = next(iter(per_seed.values())).keys()
+        ref_shape[label] = {g: round(sum(v[g] for v in per_seed.values()) / len(per_seed) / 1e4, 2) for g in groups}
     return {"value": reps * n / dt / 1e9, "unit": "Gmul/s", "cores": threads, "kind": "port",
+            "reference_bench_shape_ns_per_op": ref_shape,
             "sample": "%d passes of a 2^20-element BN254 Fr mul batch (C restatement of monty_mul, "
                       "-O3, OpenMP static chunks); single-thread rate %.4f Gmul/s" % (reps, single),
             "single_thread_Gmul_per_s": single}

@@ -545,6 +545,61 @@ void fpo_bench_mul_assign(const word *modulus, size_t n, const word *elem, size_
     memcpy(out, acc, n * sizeof(word));
 }
 
+/* ---- benches/field_ops_bench_common.rs:15-107, the whole reference bench shape on ONE
+ * element: `iters` (10000 there) repetitions of Mul ref by ref, Mul assign, Add ref to ref,
+ * Add assign, Div ref by ref, Negation, Sum over 10, Product over 10.  Writes nanoseconds
+ * per group call (i.e. per `iters` operations, as criterion reports them) to ns[0..7].
+ * `sink` keeps the results alive (black_box). */
+#include <time.h>
+static double now_ns(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec * 1e9 + (double)ts.tv_nsec;
+}
+int fpo_bench_reference_shape(const word *modulus, size_t n, const word *elem, size_t iters, double *ns, word *sink)
+{
+    word inv, one[FPO_MAX_LIMBS], r2[FPO_MAX_LIMBS], acc[FPO_MAX_LIMBS], t[FPO_MAX_LIMBS], q[FPO_MAX_LIMBS];
+    word v[10 * FPO_MAX_LIMBS];
+    volatile word keep = 0;
+    if (fpo_params(modulus, n, &inv, one, r2)) return 1;
+    for (int i = 0; i < 10; i++) memcpy(v + (size_t)i * n, elem, n * sizeof(word));
+    double t0 = now_ns();
+    for (size_t i = 0; i < iters; i++) { fpo_monty_mul(elem, elem, modulus, t, n); keep ^= t[0]; }      /* :15-25 */
+    ns[0] = now_ns() - t0; t0 = now_ns();
+    memcpy(acc, elem, n * sizeof(word));
+    for (size_t i = 0; i < iters; i++) { fpo_monty_mul(acc, elem, modulus, t, n); memcpy(acc, t, n * sizeof(word)); }  /* :27-39 */
+    keep ^= acc[0];
+    ns[1] = now_ns() - t0; t0 = now_ns();
+    for (size_t i = 0; i < iters; i++) { fpo_add_mod(elem, elem, modulus, t, n); keep ^= t[0]; }          /* :41-51 */
+    ns[2] = now_ns() - t0; t0 = now_ns();
+    memcpy(acc, elem, n * sizeof(word));
+    for (size_t i = 0; i < iters; i++) { fpo_add_mod(acc, elem, modulus, t, n); memcpy(acc, t, n * sizeof(word)); }    /* :53-65 */
+    keep ^= acc[0];
+    ns[3] = now_ns() - t0; t0 = now_ns();
+    for (size_t i = 0; i < iters; i++) {                                                               /* :67-77 div = mul by inv */
+        if (fpo_inv(elem, modulus, r2, q, n)) fpo_monty_mul(elem, q, modulus, t, n);
+        keep ^= t[0];
+    }
+    ns[4] = now_ns() - t0; t0 = now_ns();
+    for (size_t i = 0; i < iters; i++) { fpo_neg_mod(elem, modulus, t, n); keep ^= t[0]; }                /* :79-89 */
+    ns[5] = now_ns() - t0; t0 = now_ns();
+    for (size_t i = 0; i < iters; i++) {                                                               /* :93-99 */
+        memset(acc, 0, n * sizeof(word));
+        for (int j = 0; j < 10; j++) { fpo_add_mod(acc, v + (size_t)j * n, modulus, t, n); memcpy(acc, t, n * sizeof(word)); }
+        keep ^= acc[0];
+    }
+    ns[6] = now_ns() - t0; t0 = now_ns();
+    for (size_t i = 0; i < iters; i++) {                                                               /* :101-107 */
+        memcpy(acc, one, n * sizeof(word));
+        for (int j = 0; j < 10; j++) { fpo_monty_mul(acc, v + (size_t)j * n, modulus, t, n); memcpy(acc, t, n * sizeof(word)); }
+        keep ^= acc[0];
+    }
+    ns[7] = now_ns() - t0;
+    *sink = keep;
+    return 0;
+}
+
 /* ======================= pow =====================
  * ---- src/helpers/crypto_bigint.rs:441-454 conditional_borrowing_sub_assign */
 static int conditional_borrowing_sub_assign(word *lhs, const word *rhs, int choice, size_t n)

@@ -168,5 +168,26 @@ class Oracle:
         return out
 
 
+REF_BENCH_GROUPS = ("Mul ref by ref", "Mul assign", "Add ref to ref", "Add assign", "Div ref by ref", "Negation",
+                    "Sum", "Product")
+REF_BENCH_SEEDS = (695962179703, 2345695962179703, 111111111111111111, 12345678124578658568)  # field_ops_bench_common.rs:121-124
+
+
+def bench_reference_shape(modulus: int, n64: int, iters: int = 10000):
+    """The reference's criterion groups (benches/field_ops_bench_common.rs) on this CPU: for each of its
+    four seeds projected into the field, nanoseconds per `iters` operations of each group, single core."""
+    o = Oracle(modulus, n64)
+    out = {}
+    for seed in REF_BENCH_SEEDS:
+        elem = o.to_mont(int_to_words(seed % (1 << (64 * n64)), n64).reshape(1, -1)).reshape(-1)
+        ns = np.zeros(8, dtype=np.float64)
+        sink = np.zeros(1, dtype=np.uint64)
+        rc = lib().fpo_bench_reference_shape(_p(o.mod), ctypes.c_size_t(n64), _p(elem), ctypes.c_size_t(iters),
+                                             ns.ctypes.data_as(ctypes.c_void_p), _p(sink))
+        assert rc == 0
+        out[str(seed)] = {g: float(v) for g, v in zip(REF_BENCH_GROUPS, ns)}
+    return out
+
+
 def max_threads():
     return lib().fpo_max_threads()
