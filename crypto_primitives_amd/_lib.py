@@ -33,6 +33,8 @@ SIGNATURES = {
     "fpgpu_batch_inv_dev": (_int, [_vp, _vp, _vp, _vp, _sz, _vp, _sz, _vp]),
     "fpgpu_matvec_workspace_bytes": (_sz, [_vp, _sz, _sz]),
     "fpgpu_matvec_dev": (_int, [_vp, _vp, _sz, _sz, _vp, _vp, _vp, _sz, _vp]),
+    "fpgpu_spmv_dev": (_int, [_vp, _vp, _vp, _sz, _sz, _sz, _vp, _vp, _vp]),
+    "fpgpu_spmv": (_int, [_vp, _vp, _vp, _sz, _sz, _sz, _vp, _vp]),
     "fpgpu_matmul_workspace_bytes": (_sz, [_vp, _sz, _sz, _sz]),
     "fpgpu_matmul_dev": (_int, [_vp, _vp, _vp, _vp, _sz, _sz, _sz, _vp, _sz, _vp]),
     "fpgpu_fill_random_dev": (_int, [_vp, _vp, _sz, _u64, _vp]),

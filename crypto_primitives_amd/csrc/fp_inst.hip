@@ -212,6 +212,19 @@ void Launch<N>::fill_random(const fpgpu_ctx* ctx, void* out, size_t n, uint64_t 
 }
 
 template <int N>
+void Launch<N>::spmv(const fpgpu_ctx* ctx, const void* vals, const uint32_t* colidx, size_t rows, size_t cols,
+                     uint32_t density, const void* x, void* y, hipStream_t s) {
+    uint32_t log2g = 0;
+    while ((1u << log2g) < density && log2g < 6) log2g++;
+    const size_t lanes = rows << log2g;
+    size_t blocks = (lanes + kBlock - 1) / kBlock;
+    if (blocks > (1u << 20)) blocks = 1u << 20;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL((k_spmv<N>), dim3((unsigned)blocks), dim3(kBlock), 0, s, (const uint32_t*)vals, colidx,
+                       (const uint32_t*)x, (uint32_t*)y, rows, cols, density, log2g, make_params<N>(ctx));
+}
+
+template <int N>
 void Launch<N>::pow(const fpgpu_ctx* ctx, const void* a, const uint32_t* exp32, int top_bit, void* out, size_t n,
                     hipStream_t s) {
     PowExp e;

@@ -477,6 +477,53 @@ __global__ __launch_bounds__(kBlock) void k_matvec(const uint32_t* __restrict__ 
     }
 }
 
+// ---- sparse mat-vec over SparseMatrix<T> (src/matrix.rs:46-61: `density`
+// cells (column index, value) per row, rows stored back to back) -----------------------
+// y[i] = sum_{j < density} mul(val[i*density + j], x[col[i*density + j]]): the same fold of mul and
+// add as the dense product.  G = 2^log2g lanes share a row (G is the power of two covering the
+// density, at most 64): values are read coalesced, x is gathered, products are accumulated
+// lazily per lane (as k_matvec) and the G partial residues are summed with a butterfly.
+// A column index >= cols contributes nothing (the host entry point rejects such input).
+template <int N>
+__global__ __launch_bounds__(kBlock) void k_spmv(const uint32_t* __restrict__ vals, const uint32_t* __restrict__ colidx,
+                                                 const uint32_t* __restrict__ x, uint32_t* __restrict__ y, size_t rows,
+                                                 size_t cols, uint32_t density, uint32_t log2g, const FpParams<N> P) {
+    const uint32_t G = 1u << log2g;
+    const size_t rows_per_pass = ((size_t)gridDim.x * kBlock) >> log2g;
+    const size_t gid = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t sub = (uint32_t)(gid & (G - 1));
+    for (size_t row0 = 0; row0 < rows; row0 += rows_per_pass) {  // same trip count for every lane: shuffles below
+        const size_t row = row0 + (gid >> log2g);
+        uint32_t S[2 * N];
+#pragma unroll
+        for (int l = 0; l < 2 * N; l++) S[l] = 0;
+        if (row < rows) {
+            for (uint32_t j = sub; j < density; j += G) {
+                const size_t cell = row * density + j;
+                const uint32_t c = colidx[cell];
+                if (c < cols) {
+                    uint32_t a[1][N], b[1][N], prod[2 * N];
+                    load_elem<N>(a[0], vals, cell);
+                    load_elem<N>(b[0], x, c);
+                    mul_wide_sum<N, 1>(prod, a, b);
+                    wide_acc_add<N>(S, prod, P);
+                }
+            }
+        }
+        uint32_t acc[N];
+        mont_redc_wide<N>(acc, S, P);
+        for (uint32_t off = G >> 1; off >= 1; off >>= 1) {
+            uint32_t o[N], r[N];
+#pragma unroll
+            for (int l = 0; l < N; l++) o[l] = __shfl_xor(acc[l], (int)off, 64);
+            mod_add<N>(r, acc, o, P);
+#pragma unroll
+            for (int l = 0; l < N; l++) acc[l] = r[l];
+        }
+        if (row < rows && sub == 0) store_elem<N>(y, row, acc);
+    }
+}
+
 // ---- dense mat-mul: C = A (m x k) * B (k x n), LDS-tiled -------------------------
 // 16 x 16 outputs per workgroup, one per lane; K walked in 16-wide tiles staged in
 // LDS.  First correct version; the register-tiled lazy-reduction variant for the

@@ -111,6 +111,8 @@ struct Launch {
                        void* workspace, size_t workspace_bytes,
                        hipStream_t s);
     static void fill_random(const fpgpu_ctx* ctx, void* out, size_t n, uint64_t seed, hipStream_t s);
+    static void spmv(const fpgpu_ctx* ctx, const void* vals, const uint32_t* colidx, size_t rows, size_t cols,
+                     uint32_t density, const void* x, void* y, hipStream_t s);
     static void pow(const fpgpu_ctx* ctx, const void* a, const uint32_t* exp32, int top_bit, void* out, size_t n,
                     hipStream_t s);
     static void fold(bool product, const fpgpu_ctx* ctx, const void* v, size_t n, void* out, void* ws,

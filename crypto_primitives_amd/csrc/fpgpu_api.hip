@@ -315,6 +315,24 @@ int fpgpu_matvec_dev(const fpgpu_ctx* ctx, const void* A, size_t rows, size_t co
     return FPGPU_OK;
 }
 
+int fpgpu_spmv_dev(const fpgpu_ctx* ctx, const void* vals, const uint32_t* col_idx, size_t rows, size_t cols,
+                   size_t density, const void* x, void* y, void* stream) {
+    if (!ctx) return fail(FPGPU_ERR_SHAPE, "null context");
+    if (rows == 0) return FPGPU_OK;
+    if (density > 0xffffffffu || cols > 0xffffffffu || rows > ((size_t)1 << 40) / (density ? density : 1))
+        return fail(FPGPU_ERR_SHAPE, "sparse matrix too large");
+    CHECK(check_ptr(ctx, y, "y"));
+    if (density != 0) {
+        CHECK(check_ptr(ctx, vals, "vals"));
+        if (!col_idx || (uintptr_t)col_idx % 4) return fail(FPGPU_ERR_SHAPE, "null or misaligned pointer: col_idx");
+        if (cols) CHECK(check_ptr(ctx, x, "x"));
+    }
+    hipStream_t s = (hipStream_t)stream;
+    DISPATCH_N64(ctx->n64, Launch<N>::spmv(ctx, vals, col_idx, rows, cols, (uint32_t)density, x, y, s));
+    HIP_TRY(hipGetLastError());
+    return FPGPU_OK;
+}
+
 size_t fpgpu_matmul_workspace_bytes(const fpgpu_ctx* ctx, size_t m, size_t k, size_t n) {
     if (!ctx) return 0;
     const MfmaPlan pl = make_mfma_plan(ctx->n64, m, k, n);
@@ -504,6 +522,33 @@ int fpgpu_matvec(const fpgpu_ctx* ctx, const uint64_t* A, size_t rows, size_t co
     const size_t ws_bytes = fpgpu_matvec_workspace_bytes(ctx, rows, cols);
     if (ws_bytes) CHECK(ws.alloc(ws_bytes));
     CHECK(fpgpu_matvec_dev(ctx, dA.p, rows, cols, dx.p, dy.p, ws_bytes ? ws.p : nullptr, ws_bytes, nullptr));
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    HIP_TRY(hipMemcpy(y, dy.p, rows * esz, hipMemcpyDeviceToHost));
+    return FPGPU_OK;
+}
+
+int fpgpu_spmv(const fpgpu_ctx* ctx, const uint64_t* vals, const uint32_t* col_idx, size_t rows, size_t cols,
+               size_t density, const uint64_t* x, uint64_t* y) {
+    if (!ctx) return fail(FPGPU_ERR_SHAPE, "null context");
+    if (rows == 0) return FPGPU_OK;
+    if (!y || (density && (!vals || !col_idx)) || (density && cols && !x)) return fail(FPGPU_ERR_SHAPE, "null host pointer");
+    if (density && rows > ((size_t)1 << 40) / density) return fail(FPGPU_ERR_SHAPE, "sparse matrix too large");
+    // the reference indexes x[col] and panics out of bounds (src/matrix.rs cells are (usize, T)): reject here
+    for (size_t i = 0; i < rows * density; i++)
+        if (col_idx[i] >= cols) return fail(FPGPU_ERR_SHAPE, "spmv: column index out of range");
+    CHECK(require_device());
+    size_t esz = ctx->n64 * 8, cells = rows * density;
+    DevBuf dv, dc, dx, dy;
+    CHECK(dv.alloc(cells * esz));
+    CHECK(dc.alloc(cells * 4));
+    CHECK(dx.alloc(cols * esz));
+    CHECK(dy.alloc(rows * esz));
+    if (cells) {
+        HIP_TRY(hipMemcpy(dv.p, vals, cells * esz, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(dc.p, col_idx, cells * 4, hipMemcpyHostToDevice));
+    }
+    if (cols) HIP_TRY(hipMemcpy(dx.p, x, cols * esz, hipMemcpyHostToDevice));
+    CHECK(fpgpu_spmv_dev(ctx, dv.p, (const uint32_t*)dc.p, rows, cols, density, dx.p, dy.p, nullptr));
     HIP_TRY(hipStreamSynchronize(nullptr));
     HIP_TRY(hipMemcpy(y, dy.p, rows * esz, hipMemcpyDeviceToHost));
     return FPGPU_OK;

@@ -148,6 +148,17 @@ class MontyField:
         check(self._lib.fpgpu_matvec(self._h, _ptr(A), rows, cols, _ptr(x), _ptr(y)))
         return y
 
+    def spmv(self, vals, col_idx, rows, cols, density, x):
+        """SparseMatrix (fixed `density` cells per row) times vector; col_idx is uint32[rows*density]."""
+        vals, x = _np(vals, self.n64), _np(x, self.n64)
+        col_idx = np.ascontiguousarray(col_idx, dtype=np.uint32)
+        if vals.shape[0] != rows * density or col_idx.shape[0] != rows * density or x.shape[0] != cols:
+            raise ValueError("sparse matrix / vector shape mismatch")
+        y = np.zeros((rows, self.n64), dtype=np.uint64)
+        check(self._lib.fpgpu_spmv(self._h, _ptr(vals), col_idx.ctypes.data_as(ctypes.c_void_p), rows, cols, density,
+                                   _ptr(x), _ptr(y)))
+        return y
+
     def matmul(self, A, B, m, k, n):
         A, B = _np(A, self.n64), _np(B, self.n64)
         if A.shape[0] != m * k or B.shape[0] != k * n:

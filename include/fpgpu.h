@@ -130,6 +130,14 @@ int fpgpu_batch_inv_dev(const fpgpu_ctx *ctx, const void *x, void *out, uint8_t 
 size_t fpgpu_matvec_workspace_bytes(const fpgpu_ctx *ctx, size_t rows, size_t cols);
 int fpgpu_matvec_dev(const fpgpu_ctx *ctx, const void *A, size_t rows, size_t cols, const void *x,
                      void *y, void *workspace, size_t workspace_bytes, void *stream);
+/* Sparse mat-vec over SparseMatrix<T> (src/matrix.rs:46-61: a fixed number `density` of
+ * (column index, value) cells per row, rows back to back):
+ * y[i] = sum_{j<density} mul(vals[i*density + j], x[col_idx[i*density + j]]).  The reference's
+ * cells are Rust tuples (usize, T) with no defined layout, so the binding passes the two halves
+ * as separate arrays; indices are 32-bit and must be < cols (the host variant checks them and
+ * returns FPGPU_ERR_SHAPE where the reference would panic; the device variant skips such cells). */
+int fpgpu_spmv_dev(const fpgpu_ctx *ctx, const void *vals, const uint32_t *col_idx, size_t rows, size_t cols,
+                   size_t density, const void *x, void *y, void *stream);
 /* C[i*n + j] = sum_l mul(A[i*k + l], B[l*n + j]); A is m x k, B is k x n, C is m x n.
  * `workspace` is optional device scratch (256-byte aligned) of at least
  * fpgpu_matmul_workspace_bytes(ctx, m, k, n) bytes; with it, single-limb fields (n64 == 1,
@@ -162,6 +170,8 @@ int fpgpu_product(const fpgpu_ctx *ctx, const uint64_t *v, size_t n, uint64_t *o
 int fpgpu_batch_inv(const fpgpu_ctx *ctx, const uint64_t *x, uint64_t *out, uint8_t *zero_flags, size_t n);
 int fpgpu_matvec(const fpgpu_ctx *ctx, const uint64_t *A, size_t rows, size_t cols, const uint64_t *x,
                  uint64_t *y);
+int fpgpu_spmv(const fpgpu_ctx *ctx, const uint64_t *vals, const uint32_t *col_idx, size_t rows, size_t cols,
+               size_t density, const uint64_t *x, uint64_t *y);
 int fpgpu_matmul(const fpgpu_ctx *ctx, const uint64_t *A, const uint64_t *B, uint64_t *C, size_t m,
                  size_t k, size_t n);
 

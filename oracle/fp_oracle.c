@@ -508,6 +508,27 @@ int fpo_matvec(const word *modulus, size_t n, const word *A, size_t rows, size_t
     return 0;
 }
 
+/* Sparse mat-vec over SparseMatrix (src/matrix.rs:46-61: `density` cells (col, value) per row,
+ * rows back to back): y[i] = sum_refs_j mul(val[i][j], x[col[i][j]]).  Returns 1 on an index out
+ * of range (the reference would panic on x[col]). */
+int fpo_spmv(const word *modulus, size_t n, const word *vals, const uint32_t *col, size_t rows, size_t cols,
+             size_t density, const word *x, word *y)
+{
+    for (size_t i = 0; i < rows; i++) {
+        word acc[FPO_MAX_LIMBS], t[FPO_MAX_LIMBS], s[FPO_MAX_LIMBS];
+        memset(acc, 0, n * sizeof(word));
+        for (size_t j = 0; j < density; j++) {
+            size_t cell = i * density + j;
+            if (col[cell] >= cols) return 1;
+            fpo_monty_mul(vals + cell * n, x + (size_t)col[cell] * n, modulus, t, n);
+            fpo_add_mod(acc, t, modulus, s, n);
+            memcpy(acc, s, n * sizeof(word));
+        }
+        memcpy(y + i * n, acc, n * sizeof(word));
+    }
+    return 0;
+}
+
 /* Mat-mul C[m x nn] = A[m x k] * B[k x nn], row-major, same fold per output. */
 int fpo_matmul(const word *modulus, size_t n, const word *A, const word *B, word *C,
                size_t m, size_t k, size_t nn, int threads)

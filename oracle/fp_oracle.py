@@ -137,6 +137,17 @@ class Oracle:
                          ctypes.c_size_t(cols), _p(x), _p(y), ctypes.c_int(threads))
         return y
 
+    def spmv(self, vals, col_idx, rows, cols, density, x):
+        vals, x = _arr(vals, self.n64), _arr(x, self.n64)
+        col_idx = np.ascontiguousarray(col_idx, dtype=np.uint32)
+        assert vals.shape[0] == rows * density == col_idx.shape[0] and x.shape[0] == cols
+        y = np.zeros((rows, self.n64), dtype=np.uint64)
+        rc = lib().fpo_spmv(_p(self.mod), ctypes.c_size_t(self.n64), _p(vals), col_idx.ctypes.data_as(ctypes.c_void_p),
+                            ctypes.c_size_t(rows), ctypes.c_size_t(cols), ctypes.c_size_t(density), _p(x), _p(y))
+        if rc:
+            raise IndexError("column index out of range")
+        return y
+
     def matmul(self, A, B, m, k, n, threads=1):
         A = _arr(A, self.n64)
         B = _arr(B, self.n64)

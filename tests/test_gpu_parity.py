@@ -245,6 +245,32 @@ def test_matvec_multi_term_passes(cpa, T, monkeypatch):
             assert np.array_equal(f.matvec(A, rows, cols, x), o.matvec(A, rows, cols, x, threads=0))
 
 
+@pytest.mark.parametrize("shape", [(1, 1, 1), (5, 9, 3), (300, 1000, 7), (33, 50, 64), (17, 400, 100), (9, 70, 200),
+                                   (4, 6, 0), (70001, 4096, 4)])
+def test_spmv_vs_oracle(cpa, shape):
+    """SparseMatrix (src/matrix.rs:46-61: `density` (column, value) cells per row) times vector ==
+    the oracle's fold of mul then add; repeated columns inside a row are legal and summed."""
+    rows, cols, density = shape
+    rng = np.random.default_rng(rows + cols + density)
+    for name in ("bn254_fr", "goldilocks", "bls12_381_fq"):
+        g = load_golden(name)
+        p, n64 = h2i(g["modulus"]), g["n64"]
+        f, o = field_of(cpa, g), oracle_of(g)
+        vals = ints_to_array(synth_elements(p, n64, rows * density, 91), n64)
+        x = ints_to_array(synth_elements(p, n64, cols, 92), n64)
+        col = rng.integers(0, cols, size=rows * density, dtype=np.uint32)
+        want = o.spmv(vals, col, rows, cols, density, x)
+        assert np.array_equal(f.spmv(vals, col, rows, cols, density, x), want), name
+
+
+def test_spmv_rejects_out_of_range_column(cpa):
+    f = cpa.MontyField(cpa.BN254_FR, 4)
+    vals = np.ones((2, 4), dtype=np.uint64)
+    x = np.ones((3, 4), dtype=np.uint64)
+    with pytest.raises(cpa.FpgpuError):
+        f.spmv(vals, np.array([0, 3], dtype=np.uint32), 1, 3, 2, x)
+
+
 @pytest.mark.parametrize("shape", [(1, 1, 1), (16, 16, 16), (33, 70, 17), (100, 129, 65)])
 def test_matmul_vs_oracle(cpa, shape):
     m, k, n = shape

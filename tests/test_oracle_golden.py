@@ -92,3 +92,26 @@ def test_openmp_driver_matches_serial():
     a = rng.integers(0, 1 << 60, size=(5000, 4), dtype=np.uint64)
     b = rng.integers(0, 1 << 60, size=(5000, 4), dtype=np.uint64)
     assert np.array_equal(o.mul(a, b, threads=1), o.mul(a, b, threads=4))
+
+
+def test_spmv_against_python_ints():
+    """Sparse mat-vec (SparseMatrix, src/matrix.rs:46-61) == the same fold in Python ints;
+    the reference holds no fixture for it (no arithmetic lives in matrix.rs): parity unpinned
+    by the reference's own tests, determined by canonical residues."""
+    import random
+    rng = random.Random(11)
+    for p, n64 in ((0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001, 4), (0xFFFFFFFF00000001, 1)):
+        o = Oracle(p, n64)
+        Rinv = pow(1 << (64 * n64), -1, p)
+        for rows, cols, density in ((5, 9, 3), (1, 1, 1), (7, 4, 6), (3, 5, 0)):
+            vals = [rng.randrange(p) for _ in range(rows * density)]
+            col = [rng.randrange(cols) for _ in range(rows * density)]
+            x = [rng.randrange(p) for _ in range(cols)]
+            want = [sum(vals[i * density + j] * x[col[i * density + j]] * Rinv for j in range(density)) % p
+                    for i in range(rows)]
+            got = o.spmv(ints_to_array(vals, n64), np.array(col, dtype=np.uint32), rows, cols, density,
+                         ints_to_array(x, n64))
+            assert array_to_ints(got) == want
+    import pytest
+    with pytest.raises(IndexError):
+        o.spmv(ints_to_array([1], 1), np.array([2], dtype=np.uint32), 1, 2, 1, ints_to_array([1, 1], 1))
