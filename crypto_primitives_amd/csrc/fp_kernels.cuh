@@ -4,6 +4,7 @@
 #pragma once
 #include "fp_device.cuh"
 #include "fp_launch.hpp"
+#include "fp_unsat.cuh"
 
 namespace fpgpu {
 
@@ -37,22 +38,28 @@ __global__ __launch_bounds__(kBlock) void k_elementwise(const uint32_t* __restri
 }
 
 // ---- dependent multiply chain (VALU-bound; "Mul assign" bench shape) -----------
+// Chain<N> (fp_unsat.cuh): from N = 6 limbs on the chain runs on unsaturated 29-bit limbs (no
+// carry instruction inside a column) and the running value stays in [0, 2p) between steps where
+// the modulus leaves two spare bits; it is made canonical once, before the store.
 template <int N>
 __global__ __launch_bounds__(kBlock) void k_mul_chain(const uint32_t* __restrict__ a,
                                                       const uint32_t* __restrict__ b,
                                                       uint32_t* __restrict__ out, size_t n, uint32_t iters,
                                                       const FpParams<N> P) {
     const size_t stride = (size_t)gridDim.x * kBlock;
+    Chain<N> acc(P);
     for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
-        uint32_t acc[N], y[N], r[N];
-        load_elem<N>(acc, a, i);
-        load_elem<N>(y, b, i);
-        for (uint32_t it = 0; it < iters; it++) {
-            mont_mul<N>(r, acc, y, P);
-#pragma unroll
-            for (int l = 0; l < N; l++) acc[l] = r[l];
+        uint32_t w[N];
+        typename Chain<N>::Op y;
+        load_elem<N>(w, b, i);
+        Chain<N>::prep(y, w);
+        load_elem<N>(w, a, i);
+        if (iters) {   // zero iterations hand the input back untouched
+            acc.set(w);
+            for (uint32_t it = 0; it < iters; it++) acc.mul_op(y);
+            acc.get_canonical(w);
         }
-        store_elem<N>(out, i, acc);
+        store_elem<N>(out, i, w);
     }
 }
 
@@ -281,6 +288,11 @@ __device__ __forceinline__ bool mont_inv_gcd(uint32_t (&out)[N], const uint32_t 
 //   (recurse on the totals until few remain, invert those with the GCD kernel)
 //   k_binv_down: walks each chain backwards with the inverted total.
 // Chain index of element e at tile size T = kBlock*C: (e / T) * kBlock + (e % kBlock).
+// The running products are Chain<N> values (fp_unsat.cuh): from N = 6 limbs on they live in
+// unsaturated 29-bit limbs and, where the modulus leaves two spare bits, in [0, 2p): prefixes
+// and totals are then stored unreduced (they fit the container), and only the results
+// k_binv_down writes are canonical.  Both kernels load the next element of the chain before they
+// multiply by the current one, so a wave always has a load in flight behind its arithmetic.
 template <int N, int C, bool LEVEL0>
 __global__ __launch_bounds__(kBlock) void k_binv_up(const uint32_t* __restrict__ x, uint32_t* __restrict__ prefix,
                                                     uint32_t* __restrict__ totals, uint8_t* __restrict__ zero_flags,
@@ -289,12 +301,19 @@ __global__ __launch_bounds__(kBlock) void k_binv_up(const uint32_t* __restrict__
     const size_t chain = (size_t)blockIdx.x * kBlock + threadIdx.x;
     size_t e = tile + threadIdx.x;
     if (e >= n) return;  // chain empty (only in the last tile)
-    uint32_t run[N], v[N], t[N];
-    set_limbs<N>(run, P.one);
+    Chain<N> run(P);
+    uint32_t w[N], v[N], vn[N];
+    set_limbs<N>(w, P.one);
+    run.set(w);
+    load_elem<N>(v, x, e);
 #pragma unroll 1
     for (int k = 0; k < C && e < n; k++, e += kBlock) {
-        load_elem<N>(v, x, e);
-        store_elem<N>(prefix, e, run);
+        // next element of the chain (the current one again at the end: an unconditional load
+        // keeps the loop free of a conditional register merge)
+        const bool more = k + 1 < C && e + kBlock < n;
+        load_elem<N>(vn, x, more ? e + kBlock : e);
+        run.get(w);
+        store_elem<N>(prefix, e, w);
         bool z = is_zero<N>(v);
         if constexpr (LEVEL0) {
             if (zero_flags) zero_flags[e] = z ? 1 : 0;
@@ -302,13 +321,12 @@ __global__ __launch_bounds__(kBlock) void k_binv_up(const uint32_t* __restrict__
         // Level 0 takes a zero as one (it is flagged, its slot gets 0).  Above level 0 a
         // zero total (composite modulus only) must poison its group: keep multiplying so
         // the zero reaches the top, where the GCD inverse rejects it.
-        if (!z || !LEVEL0) {
-            mont_mul<N>(t, run, v, P);
+        if (!z || !LEVEL0) run.mul(v);
 #pragma unroll
-            for (int l = 0; l < N; l++) run[l] = t[l];
-        }
+        for (int l = 0; l < N; l++) v[l] = vn[l];
     }
-    store_elem<N>(totals, chain, run);
+    run.get(w);
+    store_elem<N>(totals, chain, w);
 }
 
 // inv_totals[chain] holds the inverse of the chain total; poisoned[] (may be null
@@ -324,27 +342,32 @@ __global__ __launch_bounds__(kBlock) void k_binv_down(const uint32_t* __restrict
     // number of elements in this chain
     size_t cnt = (n - first + kBlock - 1) / kBlock;
     if (cnt > (size_t)C) cnt = C;
-    uint32_t run[N], v[N], pre[N], t[N];
-    load_elem<N>(run, inv_totals, chain);
+    Chain<N> run(P);
+    uint32_t w[N], v[N], pre[N], vn[N], pn[N];
+    load_elem<N>(w, inv_totals, chain);
+    run.set(w);
+    load_elem<N>(v, x, first + (cnt - 1) * kBlock);
+    load_elem<N>(pre, out, first + (cnt - 1) * kBlock);  // exclusive prefix written by k_binv_up
 #pragma unroll 1
     for (size_t k = cnt; k-- > 0;) {
-        size_t e = first + k * kBlock;
-        load_elem<N>(v, x, e);
-        load_elem<N>(pre, out, e);  // exclusive prefix written by k_binv_up
+        const size_t e = first + k * kBlock;
+        const size_t en = k > 0 ? e - kBlock : e;   // next element down the chain (see k_binv_up)
+        load_elem<N>(vn, x, en);
+        load_elem<N>(pn, out, en);
         bool z = LEVEL0 && is_zero<N>(v);
         if (z) {
 #pragma unroll
-            for (int l = 0; l < N; l++) t[l] = 0;
-            store_elem<N>(out, e, t);
+            for (int l = 0; l < N; l++) w[l] = 0;
+            store_elem<N>(out, e, w);
         } else {
             // Above level 0 a zero total only occurs in a poisoned group (composite
             // modulus); whatever is written below it is recomputed by k_binv_fallback.
-            mont_mul<N>(t, run, pre, P);
-            store_elem<N>(out, e, t);
-            mont_mul<N>(t, run, v, P);
-#pragma unroll
-            for (int l = 0; l < N; l++) run[l] = t[l];
+            run.mul_to(w, pre);
+            store_elem<N>(out, e, w);
+            run.mul(v);
         }
+#pragma unroll
+        for (int l = 0; l < N; l++) { v[l] = vn[l]; pre[l] = pn[l]; }
     }
 }
 
@@ -588,26 +611,25 @@ template <int N>
 __global__ __launch_bounds__(kBlock) void k_pow(const uint32_t* __restrict__ a, uint32_t* __restrict__ out, size_t n,
                                                 const PowExp e, const FpParams<N> P) {
     const size_t stride = (size_t)gridDim.x * kBlock;
+    Chain<N> acc(P);   // fp_unsat.cuh: unsaturated limbs from N = 6 on, lazily reduced where the modulus allows
     for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
-        uint32_t x[N], acc[N], t[N];
-        load_elem<N>(x, a, i);
+        uint32_t w[N];
         if (e.top < 0) {
-            set_limbs<N>(acc, P.one);
+            set_limbs<N>(w, P.one);
         } else {
-#pragma unroll
-            for (int l = 0; l < N; l++) acc[l] = x[l];
-            for (int b = e.top - 1; b >= 0; b--) {
-                mont_mul<N>(t, acc, acc, P);
-#pragma unroll
-                for (int l = 0; l < N; l++) acc[l] = t[l];
-                if ((e.w[b >> 5] >> (b & 31)) & 1u) {
-                    mont_mul<N>(t, acc, x, P);
-#pragma unroll
-                    for (int l = 0; l < N; l++) acc[l] = t[l];
+            typename Chain<N>::Op x;
+            load_elem<N>(w, a, i);
+            if (e.top > 0) {   // exponent one hands the input back untouched
+                Chain<N>::prep(x, w);
+                acc.set(w);
+                for (int b = e.top - 1; b >= 0; b--) {
+                    acc.square();
+                    if ((e.w[b >> 5] >> (b & 31)) & 1u) acc.mul_op(x);
                 }
+                acc.get_canonical(w);
             }
         }
-        store_elem<N>(out, i, acc);
+        store_elem<N>(out, i, w);
     }
 }
 
@@ -634,9 +656,20 @@ __global__ __launch_bounds__(kBlock) void k_fold(const uint32_t* __restrict__ v,
         for (int l = 0; l < N; l++) acc[l] = 0;
     }
     const size_t stride = (size_t)gridDim.x * kBlock;
-    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
-        load_elem<N>(o, v, i);
-        fold2<N, PROD>(acc, o, P);
+    if constexpr (PROD) {
+        // the streaming part of the product is a Chain<N> (fp_unsat.cuh), lazily reduced where possible
+        Chain<N> run(P);
+        run.set(acc);
+        for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+            load_elem<N>(o, v, i);
+            run.mul(o);
+        }
+        run.get_canonical(acc);
+    } else {
+        for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+            load_elem<N>(o, v, i);
+            fold2<N, PROD>(acc, o, P);
+        }
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {

@@ -100,12 +100,7 @@ __device__ __forceinline__ void mad_column(uint64_t& acc, const uint32_t* x, con
     if constexpr (A + S > 0) MadChunks<A, S, 0, (A + S + kMadGroup - 1) / kMadGroup>::run(acc, x, y, p, q);
 }
 
-__device__ __forceinline__ void acc_shr(uint64_t& acc, int b) {
-    uint32_t lo = (uint32_t)acc, hi = (uint32_t)(acc >> 32);
-    lo = alignbit(hi, lo, b);
-    hi >>= b;
-    acc = ((uint64_t)hi << 32) | lo;
-}
+__device__ __forceinline__ void acc_shr(uint64_t& acc, int b) { acc >>= b; }
 
 // Column K of the product-scanning Montgomery multiplication.
 template <int B, int L, int K>
@@ -176,5 +171,166 @@ __host__ __device__ inline void make_uparams(UParams<L>& U, const uint32_t* m) {
     for (int i = 0; i < 5; i++) inv *= 2u - m[0] * inv;
     U.n0inv = (0u - inv) & M;
 }
+
+// ---- the configuration the library's VALU-bound kernels use -------------------------------
+// 29-bit limbs for every compiled width: L = ceil(32 N / 29) limbs, 2L + 1 <= 37 products of
+// < 2^58 fit the 64-bit column.  Narrow fields (N < 6) stay on the saturated multiplier, which
+// needs fewer instructions there (N = 2: 10 multiplies + 8 carry adds against 21 multiplies).
+constexpr int kUB = 29;
+constexpr int kUnsatMinN = 6;
+template <int N>
+struct UF {
+    using C = UCfg<N, kUB>;
+    static constexpr int L = C::L, SH = C::SH;
+};
+
+// Wave-uniform: everything derives from the kernel argument, so the limbs of p stay in SGPRs.
+template <int N>
+__device__ __forceinline__ void uparams_from(UParams<UF<N>::L>& U, const FpParams<N>& P) {
+    constexpr int L = UF<N>::L;
+    constexpr uint32_t M = UF<N>::C::MASK;
+#pragma unroll
+    for (int i = 0; i < L; i++) {
+        const int o = i * kUB, j = o >> 5, s = o & 31;
+        uint64_t v = j < N ? P.m[j] : 0u;
+        if (j + 1 < N) v |= (uint64_t)P.m[j + 1] << 32;
+        U.p[i] = (uint32_t)(v >> s) & M;
+    }
+    U.n0inv = P.n0inv & M;  // -p^-1 mod 2^29 is the low part of -p^-1 mod 2^32
+}
+
+// Values may stay in [0, 2p) between multiplications ("lazy") when 4p <= R = 2^(32N): for
+// a, b < 2p the product step returns a*b/R + p <= 2p.  Moduli without two spare bits are
+// brought back below p after every multiplication instead.
+template <int N>
+__device__ __forceinline__ bool ulazy(const FpParams<N>& P) { return P.bitlen + 2 <= 32u * N; }
+
+// Saturated words <-> limbs, umont product with the shift that matches the reference's R:
+//   umul(r, a, bs) = a * b / 2^(32N) (mod p), < 2p for lazy inputs; bs = to_limbs<SH>(b).
+template <int N>
+__device__ __forceinline__ void uload(uint32_t (&l)[UF<N>::L], const uint32_t (&w)[N]) { to_limbs<N, kUB, 0>(l, w); }
+template <int N>
+__device__ __forceinline__ void uload_shifted(uint32_t (&l)[UF<N>::L], const uint32_t (&w)[N]) {
+    to_limbs<N, kUB, UF<N>::SH>(l, w);
+}
+template <int N>
+__device__ __forceinline__ void ustore(uint32_t (&w)[N], const uint32_t (&l)[UF<N>::L]) { from_limbs<N, kUB>(w, l); }
+template <int N>
+__device__ __forceinline__ void umul(uint32_t (&r)[UF<N>::L], const uint32_t (&a)[UF<N>::L],
+                                     const uint32_t (&bs)[UF<N>::L], const UParams<UF<N>::L>& U) {
+    umont_mul<kUB, UF<N>::L>(r, a, bs, U);
+}
+template <int N>
+__device__ __forceinline__ void ucanon(uint32_t (&r)[UF<N>::L], const UParams<UF<N>::L>& U) {
+    ucond_sub<kUB, UF<N>::L>(r, U);
+}
+// limbs of (x << SH) for normalised x < 2^(32N): the pre-shifted form of a value already in limbs
+template <int N>
+__device__ __forceinline__ void ushift(uint32_t (&r)[UF<N>::L], const uint32_t (&x)[UF<N>::L]) {
+    constexpr int L = UF<N>::L, SH = UF<N>::SH;
+    constexpr uint32_t M = UF<N>::C::MASK;
+    if constexpr (SH == 0) {
+#pragma unroll
+        for (int i = 0; i < L; i++) r[i] = x[i];
+    } else {
+        r[0] = (x[0] << SH) & M;
+#pragma unroll
+        for (int i = 1; i < L; i++) r[i] = ((x[i] << SH) | (x[i - 1] >> (kUB - SH))) & M;
+    }
+}
+
+// ---- Chain<N>: the running value of a dependent multiplication chain ----------------------
+// One interface over the two multipliers so that the chain kernels (mul chain, pow, batch
+// inversion, product fold) are written once.  Operands come and go as saturated words, the form
+// they have in memory; `get` returns the stored form of the running value, which is canonical on
+// the saturated path and may be unreduced (below 2p, it fits the container) on the lazy
+// unsaturated path; `get_canonical` always returns the residue in [0, p).  Word operands of
+// mul / mul_to may be canonical or in that stored form.
+template <int N, bool UNSAT = (N >= kUnsatMinN)>
+struct Chain;
+
+template <int N>
+struct Chain<N, false> {
+    uint32_t v[N];
+    const FpParams<N>& P;
+    __device__ __forceinline__ explicit Chain(const FpParams<N>& P_) : P(P_) {}
+    __device__ __forceinline__ void set(const uint32_t (&w)[N]) {
+#pragma unroll
+        for (int l = 0; l < N; l++) v[l] = w[l];
+    }
+    __device__ __forceinline__ void get(uint32_t (&w)[N]) const {
+#pragma unroll
+        for (int l = 0; l < N; l++) w[l] = v[l];
+    }
+    __device__ __forceinline__ void get_canonical(uint32_t (&w)[N]) const { get(w); }
+    __device__ __forceinline__ void mul(const uint32_t (&w)[N]) {
+        uint32_t t[N];
+        mont_mul<N>(t, v, w, P);
+        set(t);
+    }
+    __device__ __forceinline__ void mul_to(uint32_t (&out)[N], const uint32_t (&w)[N]) const {
+        mont_mul<N>(out, v, w, P);
+    }
+    __device__ __forceinline__ void square() {
+        uint32_t t[N];
+        mont_mul<N>(t, v, v, P);
+        set(t);
+    }
+    // a multiplier used many times, prepared once
+    typedef uint32_t Op[N];
+    static __device__ __forceinline__ void prep(Op& o, const uint32_t (&w)[N]) {
+#pragma unroll
+        for (int l = 0; l < N; l++) o[l] = w[l];
+    }
+    __device__ __forceinline__ void mul_op(const Op& o) { mul(o); }
+};
+
+template <int N>
+struct Chain<N, true> {
+    static constexpr int L = UF<N>::L;
+    uint32_t v[L];
+    UParams<L> U;
+    bool lazy;
+    __device__ __forceinline__ explicit Chain(const FpParams<N>& P) {
+        uparams_from<N>(U, P);
+        lazy = ulazy<N>(P);
+    }
+    __device__ __forceinline__ void set(const uint32_t (&w)[N]) { uload<N>(v, w); }
+    __device__ __forceinline__ void get(uint32_t (&w)[N]) const { ustore<N>(w, v); }
+    __device__ __forceinline__ void get_canonical(uint32_t (&w)[N]) const {
+        uint32_t t[L];
+#pragma unroll
+        for (int l = 0; l < L; l++) t[l] = v[l];
+        ucanon<N>(t, U);   // a no-op on a value already below p
+        ustore<N>(w, t);
+    }
+    __device__ __forceinline__ void mul_limbs(const uint32_t (&s)[L]) {
+        uint32_t t[L];
+        umul<N>(t, v, s, U);
+        if (!lazy) ucanon<N>(t, U);
+#pragma unroll
+        for (int l = 0; l < L; l++) v[l] = t[l];
+    }
+    __device__ __forceinline__ void mul(const uint32_t (&w)[N]) {
+        uint32_t s[L];
+        uload_shifted<N>(s, w);
+        mul_limbs(s);
+    }
+    __device__ __forceinline__ void mul_to(uint32_t (&out)[N], const uint32_t (&w)[N]) const {
+        uint32_t s[L], t[L];
+        uload_shifted<N>(s, w);
+        umul<N>(t, v, s, U);
+        ucanon<N>(t, U);
+        ustore<N>(out, t);
+    }
+    __device__ __forceinline__ void square() {
+        uint32_t s[L];
+        ushift<N>(s, v);
+        mul_limbs(s);
+    }
+    typedef uint32_t Op[L];
+    static __device__ __forceinline__ void prep(Op& o, const uint32_t (&w)[N]) { uload_shifted<N>(o, w); }
+    __device__ __forceinline__ void mul_op(const Op& o) { mul_limbs(o); }
+};
 
 }  // namespace fpgpu

@@ -530,3 +530,68 @@ def test_large_device_resident_properties(cpa):
     sb = b[idx].cpu().numpy().view(np.uint64)
     assert np.array_equal(ab[idx].cpu().numpy().view(np.uint64), o.mul(sa, sb))
     assert np.array_equal(t[idx].cpu().numpy().view(np.uint64), o.batch_inv(sa)[0])
+
+
+# Moduli by headroom h = 64 n64 - bitlen: from 6 limbs on, the chain kernels (mul chain, pow, batch
+# inversion, product fold) run on unsaturated 29-bit limbs and keep intermediates in [0, 2p) when
+# h >= 2, canonical after every step otherwise; both regimes and every compiled width are covered.
+_UNSAT_MODULI = [
+    ("p192 h=0", 2**192 - 2**64 - 1, 3),
+    ("secp256k1 h=0", 2**256 - 2**32 - 977, 4),
+    ("curve25519 h=1", 2**255 - 19, 4),
+    ("bn254 h=2", 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001, 4),
+    ("p127 in 256 h=129", 2**127 - 1, 4),
+    ("p320 h=0", 2**320 - 197, 5),
+    ("bls12-381 h=3", 0x1A0111EA397FE69A4B1BA7B6434BACD764774B84F38512BF6730D2A0F6B0F6241EABFFFEB153FFFFB9FEFFFFFFFFAAAB, 6),
+    ("ed448 h=0", 2**448 - 2**224 - 1, 7),
+    ("p511 h=1", 2**511 - 187, 8),
+    ("p512 h=0", 2**512 - 569, 8),
+]
+
+
+@pytest.mark.parametrize("case", _UNSAT_MODULI, ids=[c[0] for c in _UNSAT_MODULI])
+def test_chain_kernels_tight_and_lazy_moduli(cpa, case):
+    from oracle.fp_oracle import Oracle
+    _, p, n64 = case
+    f, o = cpa.MontyField(p, n64), Oracle(p, n64)
+    rnd = random.Random(p % 1000003)
+    edge = [0, 1, 2, p - 1, p - 2, p >> 1, (p >> 1) + 1]
+    xs = edge + [rnd.randrange(p) for _ in range(600 - len(edge))]
+    x = ints_to_array(xs, n64)
+    y = ints_to_array([rnd.randrange(p) for _ in xs], n64)
+    # dependent multiply chain == the oracle's mul_assign loop
+    got = f.mul_chain(x, y, 37)
+    want = x.copy()
+    for _ in range(37):
+        want = o.mul(want, y)
+    assert np.array_equal(got, want)
+    assert np.array_equal(f.mul_chain(x, y, 0), x)
+    # pow (one exponent per batch)
+    for e in (0, 1, 2, 65537, p - 2, rnd.getrandbits(64 * n64)):
+        assert np.array_equal(f.pow(x, e), o.pow(x, e, exponent_bits=64 * n64)), hex(e)
+    # batch inversion with zeros, more than one level of chains
+    big = ints_to_array([0 if i % 53 == 7 else rnd.randrange(p) for i in range(4500)], n64)
+    got, flags = f.inv(big)
+    want, wflags = o.batch_inv(big)
+    assert np.array_equal(flags, wflags) and np.array_equal(got, want)
+    # product fold
+    assert np.array_equal(f.product(big[8:53]), o.product(big[8:53]))
+    assert np.array_equal(f.product(y), o.product(y))
+
+
+def test_batch_inv_composite_modulus_wide(cpa):
+    """Poisoned groups through the unsaturated-limb kernels: odd composite (2^127 - 1)(2^89 - 1)."""
+    from oracle.fp_oracle import Oracle
+    p, n64 = (2**127 - 1) * (2**89 - 1), 4
+    f, o = cpa.MontyField(p, n64), Oracle(p, n64)
+    rnd = random.Random(5)
+    xs = [rnd.randrange(1, p) for _ in range(9000)]
+    xs[3] = (2**89 - 1) * 12345
+    xs[4000] = 0
+    xs[4001] = (2**127 - 1) * 3
+    xs[8999] = 2**89 - 1
+    x = ints_to_array(xs, n64)
+    got, flags = f.inv(x)
+    want, wflags = o.batch_inv(x)
+    assert np.array_equal(flags, wflags) and np.array_equal(got, want)
+    assert flags.sum() >= 4
