@@ -63,7 +63,7 @@ void Launch<N>::batch_inv(const fpgpu_ctx* ctx, const void* x, void* out, uint8_
                           hipStream_t s) {
     const InvPlan p = make_inv_plan(ctx->n64, n);
     const FpParams<N> P = make_params<N>(ctx);
-    const size_t tile = (size_t)kBlock * kInvC;
+    auto blocks_for = [&](int l) { return (int)((p.count[l + 1] + kBlock - 1) / kBlock); };  // one lane per chain
     auto X = [&](int l) -> const uint32_t* { return l == 0 ? (const uint32_t*)x : (const uint32_t*)(ws + p.x_off[l]); };
     auto O = [&](int l) -> uint32_t* { return l == 0 ? (uint32_t*)out : (uint32_t*)(ws + p.o_off[l]); };
     uint8_t* poisoned = (uint8_t*)(ws + p.poison_off);
@@ -71,14 +71,14 @@ void Launch<N>::batch_inv(const fpgpu_ctx* ctx, const void* x, void* out, uint8_
     (void)hipMemsetAsync(any_poisoned, 0, sizeof(uint32_t), s);
     // up-sweeps
     for (int l = 0; l < p.levels; l++) {
-        int blocks = (int)((p.count[l] + tile - 1) / tile);
+        int blocks = blocks_for(l);
         uint32_t* totals = (uint32_t*)(ws + p.x_off[l + 1]);
         if (l == 0)
-            hipLaunchKernelGGL((k_binv_up<N, kInvC, true>), dim3(blocks), dim3(kBlock), 0, s, X(0), O(0), totals,
-                               flags, p.count[0], P);
+            hipLaunchKernelGGL((k_binv_up<N, true>), dim3(blocks), dim3(kBlock), 0, s, X(0), O(0), totals,
+                               flags, p.count[0], p.c[0], P);
         else
-            hipLaunchKernelGGL((k_binv_up<N, kInvC, false>), dim3(blocks), dim3(kBlock), 0, s, X(l), O(l), totals,
-                               (uint8_t*)nullptr, p.count[l], P);
+            hipLaunchKernelGGL((k_binv_up<N, false>), dim3(blocks), dim3(kBlock), 0, s, X(l), O(l), totals,
+                               (uint8_t*)nullptr, p.count[l], p.c[l], P);
     }
     // top: exact inverses of the remaining totals, in place
     {
@@ -89,19 +89,24 @@ void Launch<N>::batch_inv(const fpgpu_ctx* ctx, const void* x, void* out, uint8_
     }
     // down-sweeps
     for (int l = p.levels - 1; l >= 0; l--) {
-        int blocks = (int)((p.count[l] + tile - 1) / tile);
+        int blocks = blocks_for(l);
         const uint32_t* inv_totals =
             (l + 1 == p.levels) ? (const uint32_t*)(ws + p.x_off[l + 1]) : (const uint32_t*)O(l + 1);
         if (l == 0)
-            hipLaunchKernelGGL((k_binv_down<N, kInvC, true>), dim3(blocks), dim3(kBlock), 0, s, X(0), O(0),
-                               inv_totals, p.count[0], P);
+            hipLaunchKernelGGL((k_binv_down<N, true>), dim3(blocks), dim3(kBlock), 0, s, X(0), O(0),
+                               inv_totals, p.count[0], p.c[0], P);
         else
-            hipLaunchKernelGGL((k_binv_down<N, kInvC, false>), dim3(blocks), dim3(kBlock), 0, s, X(l), O(l),
-                               inv_totals, p.count[l], P);
+            hipLaunchKernelGGL((k_binv_down<N, false>), dim3(blocks), dim3(kBlock), 0, s, X(l), O(l),
+                               inv_totals, p.count[l], p.c[l], P);
     }
     // composite-modulus safety net (a no-op unless a top-level total was not invertible)
-    hipLaunchKernelGGL((k_binv_fallback<N, kInvC>), dim3(grid_for(n)), dim3(kBlock), 0, s, (const uint32_t*)x,
-                       (uint32_t*)out, flags, poisoned, any_poisoned, n, p.levels, P);
+    InvChains chains{};
+    for (int l = 0; l < p.levels; l++) chains.m[l] = p.count[l + 1];
+    // (grid-stride over at most 2048 workgroups: when nothing is poisoned every wave exits at once, and a
+    // million empty workgroups would still cost 17 us of dispatch)
+    const int fb_blocks = grid_for(n) < 2048 ? grid_for(n) : 2048;
+    hipLaunchKernelGGL((k_binv_fallback<N>), dim3(fb_blocks), dim3(kBlock), 0, s, (const uint32_t*)x,
+                       (uint32_t*)out, flags, poisoned, any_poisoned, n, p.levels, chains, P);
 }
 
 template <int N>

@@ -280,38 +280,41 @@ __device__ __forceinline__ bool mont_inv_gcd(uint32_t (&out)[N], const uint32_t 
 }
 
 // ---- batch inversion: Montgomery's trick over interleaved chains -----------------
-// A "tile" is kBlock * C consecutive elements; lane t of the block owns the chain
-// {tile_base + t + kBlock * k : k < C}, so every global access is coalesced
-// (the product is commutative, any partition into chains is valid).
+// n elements form M = ceil(n / C) chains (C is chosen per level by make_inv_plan); chain c is {c + k M : k < C, c + k M < n} (the product
+// is commutative, any partition into chains is valid).  Lane t of workgroup b owns chain
+// 256 b + t, so a wave reads 64 consecutive elements, and the workgroups in flight at step k
+// sweep ONE dense range of memory [k M, (k + 1) M): every HBM channel is busy.  (The first
+// version gave each workgroup its own tile of 256 C consecutive elements; in lockstep those
+// tile strides land on a fraction of the channels, and the level-0 sweeps ran at 4.2 TB/s.)
 //   k_binv_up:   prefix[e] = product of the chain's earlier elements (zeros taken
-//                as one), total[chain] = product of the whole chain.
+//                as one), total[c] = product of the whole chain.
 //   (recurse on the totals until few remain, invert those with the GCD kernel)
 //   k_binv_down: walks each chain backwards with the inverted total.
-// Chain index of element e at tile size T = kBlock*C: (e / T) * kBlock + (e % kBlock).
+// Chain index of element e at a level with M chains: e % M.
 // The running products are Chain<N> values (fp_unsat.cuh): from N = 6 limbs on they live in
 // unsaturated 29-bit limbs and, where the modulus leaves two spare bits, in [0, 2p): prefixes
 // and totals are then stored unreduced (they fit the container), and only the results
 // k_binv_down writes are canonical.  Both kernels load the next element of the chain before they
 // multiply by the current one, so a wave always has a load in flight behind its arithmetic.
-template <int N, int C, bool LEVEL0>
+template <int N, bool LEVEL0>
 __global__ __launch_bounds__(kBlock) void k_binv_up(const uint32_t* __restrict__ x, uint32_t* __restrict__ prefix,
                                                     uint32_t* __restrict__ totals, uint8_t* __restrict__ zero_flags,
-                                                    size_t n, const FpParams<N> P) {
-    const size_t tile = (size_t)blockIdx.x * (kBlock * C);
+                                                    size_t n, const int C, const FpParams<N> P) {
+    const size_t M = (n + C - 1) / C;   // chains at this level
     const size_t chain = (size_t)blockIdx.x * kBlock + threadIdx.x;
-    size_t e = tile + threadIdx.x;
-    if (e >= n) return;  // chain empty (only in the last tile)
+    size_t e = chain;
+    if (chain >= M) return;
     Chain<N> run(P);
     uint32_t w[N], v[N], vn[N];
     set_limbs<N>(w, P.one);
     run.set(w);
     load_elem<N>(v, x, e);
 #pragma unroll 1
-    for (int k = 0; k < C && e < n; k++, e += kBlock) {
+    for (int k = 0; k < C && e < n; k++, e += M) {
         // next element of the chain (the current one again at the end: an unconditional load
         // keeps the loop free of a conditional register merge)
-        const bool more = k + 1 < C && e + kBlock < n;
-        load_elem<N>(vn, x, more ? e + kBlock : e);
+        const bool more = k + 1 < C && e + M < n;
+        load_elem<N>(vn, x, more ? e + M : e);
         run.get(w);
         store_elem<N>(prefix, e, w);
         bool z = is_zero<N>(v);
@@ -331,27 +334,26 @@ __global__ __launch_bounds__(kBlock) void k_binv_up(const uint32_t* __restrict__
 
 // inv_totals[chain] holds the inverse of the chain total; poisoned[] (may be null
 // below level 0 bookkeeping) is handled by the fallback kernel, not here.
-template <int N, int C, bool LEVEL0>
+template <int N, bool LEVEL0>
 __global__ __launch_bounds__(kBlock) void k_binv_down(const uint32_t* __restrict__ x, uint32_t* __restrict__ out,
-                                                      const uint32_t* __restrict__ inv_totals, size_t n,
+                                                      const uint32_t* __restrict__ inv_totals, size_t n, const int C,
                                                       const FpParams<N> P) {
-    const size_t tile = (size_t)blockIdx.x * (kBlock * C);
+    const size_t M = (n + C - 1) / C;   // chains at this level
     const size_t chain = (size_t)blockIdx.x * kBlock + threadIdx.x;
-    const size_t first = tile + threadIdx.x;
-    if (first >= n) return;
-    // number of elements in this chain
-    size_t cnt = (n - first + kBlock - 1) / kBlock;
-    if (cnt > (size_t)C) cnt = C;
+    const size_t first = chain;
+    if (chain >= M) return;
+    // number of elements in this chain (at most C, because C M >= n)
+    const size_t cnt = (n - first + M - 1) / M;
     Chain<N> run(P);
     uint32_t w[N], v[N], pre[N], vn[N], pn[N];
     load_elem<N>(w, inv_totals, chain);
     run.set(w);
-    load_elem<N>(v, x, first + (cnt - 1) * kBlock);
-    load_elem<N>(pre, out, first + (cnt - 1) * kBlock);  // exclusive prefix written by k_binv_up
+    load_elem<N>(v, x, first + (cnt - 1) * M);
+    load_elem<N>(pre, out, first + (cnt - 1) * M);  // exclusive prefix written by k_binv_up
 #pragma unroll 1
     for (size_t k = cnt; k-- > 0;) {
-        const size_t e = first + k * kBlock;
-        const size_t en = k > 0 ? e - kBlock : e;   // next element down the chain (see k_binv_up)
+        const size_t e = first + k * M;
+        const size_t en = k > 0 ? e - M : e;   // next element down the chain (see k_binv_up)
         load_elem<N>(vn, x, en);
         load_elem<N>(pn, out, en);
         bool z = LEVEL0 && is_zero<N>(v);
@@ -393,18 +395,21 @@ __global__ __launch_bounds__(kBlock) void k_binv_top(uint32_t* __restrict__ tota
 
 // Fallback for composite moduli: every level-0 element whose top-level group is
 // poisoned is inverted on its own (exactly the reference's per-element inv).
-// top_of(e) applies the chain map `levels` times.
-template <int N, int C>
+// The chain map e -> e % M_l, applied once per level, gives the element's top-level group.
+struct InvChains {
+    unsigned long long m[kInvMaxLevels];  // chains per level
+};
+template <int N>
 __global__ __launch_bounds__(kBlock) void k_binv_fallback(const uint32_t* __restrict__ x, uint32_t* __restrict__ out,
                                                           uint8_t* __restrict__ zero_flags,
                                                           const uint8_t* __restrict__ poisoned,
                                                           const uint32_t* __restrict__ any_poisoned, size_t n,
-                                                          int levels, const FpParams<N> P) {
+                                                          int levels, const InvChains chains, const FpParams<N> P) {
     if (any_poisoned[0] == 0) return;   // prime modulus: nothing to redo (wave-uniform exit)
     const size_t stride = (size_t)gridDim.x * kBlock;
     for (size_t e = (size_t)blockIdx.x * kBlock + threadIdx.x; e < n; e += stride) {
         size_t idx = e;
-        for (int l = 0; l < levels; l++) idx = (idx / (kBlock * C)) * kBlock + (idx % kBlock);
+        for (int l = 0; l < levels; l++) idx %= chains.m[l];
         if (!poisoned[idx]) continue;
         uint32_t v[N], r[N];
         load_elem<N>(v, x, e);

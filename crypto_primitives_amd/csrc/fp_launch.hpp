@@ -28,13 +28,18 @@ constexpr int kBlock = FPGPU_BLOCK;   // threads per workgroup of every streamin
 constexpr int kMMTile = 16;   // k_matmul output tile edge
 
 // Batch-inversion level plan (shared by the workspace-size query and the launcher).
-constexpr int kInvC = 8;          // chain length per lane
+// Chain length per lane: long chains at a big level (fewer totals to recurse on: 2^24 elements
+// cost 1.47 ms with 8 everywhere, 1.38 ms with 32 everywhere), short ones once a level has too few
+// chains to fill the chip, where a lane's serial chain is pure latency.
+constexpr int kInvCMin = 8, kInvCMax = 32;
+constexpr size_t kInvLanesWanted = 65536;   // one wave per SIMD
 constexpr size_t kInvTop = 32768; // stop recursing when this few totals remain: one exact inversion per lane
                                   // costs the same latency for 512 or 32768 lanes, two tree levels do not
 constexpr int kInvMaxLevels = 16;
 struct InvPlan {
     int levels = 0;                         // number of up-sweeps
     size_t count[kInvMaxLevels + 1] = {0};  // count[0] = n, count[l+1] = chains at level l
+    int c[kInvMaxLevels] = {0};             // chain length at level l
     size_t x_off[kInvMaxLevels + 1] = {0};  // byte offset of X_l (l >= 1) in the workspace
     size_t o_off[kInvMaxLevels + 1] = {0};  // byte offset of O_l (1 <= l < levels)
     size_t poison_off = 0;

@@ -83,13 +83,16 @@ int grid_for(size_t n) {
 
 InvPlan make_inv_plan(uint32_t n64, size_t n) {
     InvPlan p;
-    const size_t tile = (size_t)kBlock * kInvC;
     const size_t esz = (size_t)n64 * 8;
     p.count[0] = n;
     // at least one level, so the top always works on chain totals
     while (p.levels < kInvMaxLevels && (p.levels == 0 || p.count[p.levels] > kInvTop)) {
         size_t c = p.count[p.levels];
-        p.count[p.levels + 1] = (c / tile) * kBlock + std::min<size_t>(c % tile, kBlock);
+        int len = kInvCMin;
+        while (len < kInvCMax && c / (2 * (size_t)len) >= kInvLanesWanted) len *= 2;
+        if (const char* e = getenv("FPGPU_INV_C")) { int v = atoi(e); if (v >= 2 && v <= 1024) len = v; }  // tuning / tests
+        p.c[p.levels] = len;
+        p.count[p.levels + 1] = (c + len - 1) / len;   // chains of `len` elements, see k_binv_up
         p.levels++;
     }
     size_t off = 0;

@@ -179,6 +179,28 @@ def test_batch_inv_vs_oracle(cpa, n):
         assert np.array_equal(got, exp)
 
 
+@pytest.mark.parametrize("clen", ["2", "3", "32", "100"])
+def test_batch_inv_chain_lengths(cpa, clen, monkeypatch):
+    """The chain length per level is a tuning choice (FPGPU_INV_C pins it): every partition into
+    chains gives the same inverses, ragged last chains and many levels included."""
+    monkeypatch.setenv("FPGPU_INV_C", clen)
+    for name, n in (("bls12_381_fq", 70001), ("bn254_fr", 40000), ("goldilocks", 100003), ("odd_composite_128", 6000)):
+        g = load_golden(name)
+        p, n64 = h2i(g["modulus"]), g["n64"]
+        f, o = field_of(cpa, g), oracle_of(g)
+        xs = synth_elements(p, n64, n, 33)
+        for i in range(0, n, 401):
+            xs[i] = 0
+        xs[-1] = 0
+        if name == "odd_composite_128":
+            xs[17] = 3
+        x = ints_to_array(xs, n64)
+        got, flags = f.inv(x)
+        exp, eflags = o.batch_inv(x)
+        assert np.array_equal(flags, eflags), (name, clen)
+        assert np.array_equal(got, exp), (name, clen)
+
+
 def test_batch_inv_composite_modulus_poisoned_groups(cpa):
     """Odd composite modulus: non-invertible non-zero elements must come back as None
     without disturbing their neighbours (invert_odd_mod_vartime semantics)."""
