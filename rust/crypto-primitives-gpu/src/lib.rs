@@ -1,0 +1,393 @@
+//! `BatchFieldConfig`: the slice-level extension next to the reference's scalar `FieldConfig`
+//! (src/field.rs:146-187), served by libfpgpu on an MI355X.  Scalar methods stay on the CPU; every
+//! batch method returns exactly what looping the scalar method would (bit-identical canonical
+//! Montgomery residues), and fails loudly when no GPU is visible: there is no CPU fallback.
+//!
+//! NOT COMPILED in the build image (no cargo there): see ../README.md.
+//!
+//! Elements cross the FFI as contiguous little-endian `u64` words, copied through the accessors
+//! the reference already exposes (`Uint::as_words` / `from_words`,
+//! src/semiring/crypto_bigint_uint.rs:53-73; `BoxedUint::as_words` / `as_mut_words`,
+//! src/semiring/crypto_bigint_boxed_uint.rs:66-78).  No slice of elements is transmuted:
+//! crypto-bigint does not promise its structs' layout.
+
+use core::ffi::CStr;
+use core::ptr::NonNull;
+
+use crypto_primitives::{
+    crypto_bigint_boxed_monty::{BoxedMontyField, BoxedMontyFieldElement},
+    crypto_bigint_boxed_uint::BoxedUint,
+    crypto_bigint_const_monty::ConstMontyField,
+    crypto_bigint_monty::{MontyField, MontyFieldElement},
+    crypto_bigint_uint::Uint,
+    BaseFieldConfig, DenseRowMatrix, FieldConfig, FieldError, FixedConfig, SparseMatrix, Wrapper,
+};
+use crypto_bigint::modular::ConstMontyParams;
+use fpgpu_sys as sys;
+
+/// Why a batch call failed.  `InvalidModulus` mirrors `FieldError::InvalidModulus`.
+#[derive(Debug, Clone, PartialEq, Eq)]
+pub enum GpuError {
+    InvalidModulus,
+    Unsupported(String),
+    Shape(String),
+    Hip(String),
+    NoDevice,
+}
+
+impl From<GpuError> for FieldError {
+    fn from(_: GpuError) -> Self {
+        FieldError::InvalidModulus
+    }
+}
+
+fn last_error() -> String {
+    // Safety: never NULL, NUL-terminated, thread-local storage owned by the library.
+    unsafe { CStr::from_ptr(sys::fpgpu_last_error_string()) }.to_string_lossy().into_owned()
+}
+
+fn check(rc: i32) -> Result<(), GpuError> {
+    match rc {
+        sys::FPGPU_OK => Ok(()),
+        sys::FPGPU_ERR_INVALID_MODULUS => Err(GpuError::InvalidModulus),
+        sys::FPGPU_ERR_UNSUPPORTED => Err(GpuError::Unsupported(last_error())),
+        sys::FPGPU_ERR_SHAPE => Err(GpuError::Shape(last_error())),
+        sys::FPGPU_ERR_NO_DEVICE => Err(GpuError::NoDevice),
+        _ => Err(GpuError::Hip(last_error())),
+    }
+}
+
+/// Owning handle of an `fpgpu_ctx` (modulus, R, R^2, -p^-1).  Immutable after creation, so it is
+/// `Send + Sync` like the reference's configs (src/lib.rs:62-65).
+pub struct GpuCtx {
+    raw: NonNull<sys::fpgpu_ctx>,
+    n64: usize,
+}
+unsafe impl Send for GpuCtx {}
+unsafe impl Sync for GpuCtx {}
+
+impl GpuCtx {
+    /// `modulus_le`: the modulus as little-endian 64-bit words (`modulus().as_words()`).
+    pub fn new(modulus_le: &[u64]) -> Result<Self, GpuError> {
+        let mut raw = core::ptr::null_mut();
+        // Safety: `modulus_le` holds `len` words; `raw` receives an owned context or stays null.
+        check(unsafe { sys::fpgpu_ctx_create(modulus_le.as_ptr(), modulus_le.len() as u32, &mut raw) })?;
+        Ok(Self { raw: NonNull::new(raw).expect("fpgpu_ctx_create returned OK and a null context"), n64: modulus_le.len() })
+    }
+    pub fn n64(&self) -> usize {
+        self.n64
+    }
+    fn ptr(&self) -> *const sys::fpgpu_ctx {
+        self.raw.as_ptr()
+    }
+}
+
+impl Drop for GpuCtx {
+    fn drop(&mut self) {
+        // Safety: created by fpgpu_ctx_create, destroyed once.
+        unsafe { sys::fpgpu_ctx_destroy(self.raw.as_ptr()) }
+    }
+}
+
+/// How a config's elements turn into words and back.  The three reference adapters implement
+/// this; `BatchFieldConfig` is written once on top of it.
+pub trait GpuMarshal: FieldConfig {
+    /// 64-bit words per element (`LIMBS`, or `bits_precision / 64` for the boxed field).
+    fn n64(&self) -> usize;
+    /// The modulus as little-endian words.
+    fn modulus_words(&self) -> Vec<u64>;
+    /// Montgomery representative of `e`, little-endian words, into `out[..n64]`.
+    fn write_words(&self, e: &Self::Element, out: &mut [u64]);
+    /// The element whose Montgomery representative is `words[..n64]` (a canonical residue).
+    fn read_words(&self, words: &[u64]) -> Self::Element;
+    /// The exponent type's words (for `pow_batch`).
+    fn integer_words(&self, e: &Self::Integer) -> Vec<u64>;
+
+    fn gpu_ctx(&self) -> Result<GpuCtx, GpuError> {
+        GpuCtx::new(&self.modulus_words())
+    }
+    fn gather(&self, v: &[Self::Element]) -> Vec<u64> {
+        let n64 = self.n64();
+        let mut w = vec![0u64; v.len() * n64];
+        for (e, chunk) in v.iter().zip(w.chunks_exact_mut(n64)) {
+            self.write_words(e, chunk);
+        }
+        w
+    }
+    fn scatter(&self, w: &[u64]) -> Vec<Self::Element> {
+        w.chunks_exact(self.n64()).map(|c| self.read_words(c)).collect()
+    }
+}
+
+/// Slice-level methods next to `FieldConfig`.  Each is the batched form of the scalar method
+/// named in its doc line.
+pub trait BatchFieldConfig: GpuMarshal {
+    /// `mul` (src/semiring.rs:159): `out[i] = a[i] * b[i]`.
+    fn mul_batch(&self, a: &[Self::Element], b: &[Self::Element]) -> Result<Vec<Self::Element>, GpuError> {
+        binary(self, a, b, sys::fpgpu_mul)
+    }
+    /// `add` (src/semiring.rs:153).
+    fn add_batch(&self, a: &[Self::Element], b: &[Self::Element]) -> Result<Vec<Self::Element>, GpuError> {
+        binary(self, a, b, sys::fpgpu_add)
+    }
+    /// `sub` (src/semiring.rs:156).
+    fn sub_batch(&self, a: &[Self::Element], b: &[Self::Element]) -> Result<Vec<Self::Element>, GpuError> {
+        binary(self, a, b, sys::fpgpu_sub)
+    }
+    /// `neg` (src/ring.rs:45-56).
+    fn neg_batch(&self, a: &[Self::Element]) -> Result<Vec<Self::Element>, GpuError> {
+        unary(self, a, sys::fpgpu_neg)
+    }
+    /// `Square` (crypto_bigint_const_monty.rs:736-740).
+    fn square_batch(&self, a: &[Self::Element]) -> Result<Vec<Self::Element>, GpuError> {
+        unary(self, a, sys::fpgpu_sqr)
+    }
+    /// `inv` (src/field.rs:152): `None` exactly where the scalar method returns `None`.
+    fn inv_batch(&self, x: &[Self::Element]) -> Result<Vec<Option<Self::Element>>, GpuError> {
+        let ctx = self.gpu_ctx()?;
+        let xw = self.gather(x);
+        let mut ow = vec![0u64; xw.len()];
+        let mut none = vec![0u8; x.len()];
+        // Safety: all three buffers hold x.len() elements / flags.
+        check(unsafe { sys::fpgpu_batch_inv(ctx.ptr(), xw.as_ptr(), ow.as_mut_ptr(), none.as_mut_ptr(), x.len()) })?;
+        Ok(self.scatter(&ow).into_iter().zip(none).map(|(v, f)| (f == 0).then_some(v)).collect())
+    }
+    /// `div` (src/field.rs:155-157): panics with "Division by zero" if any divisor has no inverse.
+    fn div_batch(&self, a: &[Self::Element], b: &[Self::Element]) -> Result<Vec<Self::Element>, GpuError> {
+        let inv: Vec<Self::Element> = self.inv_batch(b)?.into_iter().map(|o| o.expect("Division by zero")).collect();
+        self.mul_batch(a, &inv)
+    }
+    /// `pow` (src/field.rs:160) with one exponent for the whole batch.
+    fn pow_batch(&self, x: &[Self::Element], e: &Self::Integer) -> Result<Vec<Self::Element>, GpuError> {
+        let ctx = self.gpu_ctx()?;
+        let xw = self.gather(x);
+        let ew = self.integer_words(e);
+        let mut ow = vec![0u64; xw.len()];
+        // Safety: `ew` holds `ew.len()` words (<= 8 is checked by the library).
+        check(unsafe { sys::fpgpu_pow(ctx.ptr(), xw.as_ptr(), ew.as_ptr(), ew.len() as u32, ow.as_mut_ptr(), x.len()) })?;
+        Ok(self.scatter(&ow))
+    }
+    /// `sum_refs` (src/semiring.rs:213-226) as one device fold; zero for an empty slice.
+    fn sum_batch(&self, v: &[Self::Element]) -> Result<Self::Element, GpuError> {
+        fold(self, v, sys::fpgpu_sum)
+    }
+    /// `product_refs` (src/semiring.rs:232-241); one for an empty slice.
+    fn product_batch(&self, v: &[Self::Element]) -> Result<Self::Element, GpuError> {
+        fold(self, v, sys::fpgpu_product)
+    }
+    /// `y[i] = sum_refs_j mul(A[i][j], x[j])` over `DenseRowMatrix::as_rows` (src/matrix.rs:162-164).
+    fn matvec(&self, a: &DenseRowMatrix<Self::Element>, x: &[Self::Element]) -> Result<Vec<Self::Element>, GpuError> {
+        if x.len() != a.num_cols || a.data.len() != a.num_rows * a.num_cols {
+            return Err(GpuError::Shape("matrix / vector shape mismatch".into()));
+        }
+        let ctx = self.gpu_ctx()?;
+        let (aw, xw) = (self.gather(&a.data), self.gather(x));
+        let mut yw = vec![0u64; a.num_rows * self.n64()];
+        // Safety: A holds rows*cols, x cols, y rows elements.
+        check(unsafe { sys::fpgpu_matvec(ctx.ptr(), aw.as_ptr(), a.num_rows, a.num_cols, xw.as_ptr(), yw.as_mut_ptr()) })?;
+        Ok(self.scatter(&yw))
+    }
+    /// The same fold over `SparseMatrix` (src/matrix.rs:46-61: `density` cells `(column, value)` per row).
+    fn spmv(&self, a: &SparseMatrix<Self::Element>, x: &[Self::Element]) -> Result<Vec<Self::Element>, GpuError> {
+        if x.len() != a.num_cols || a.cells.len() != a.num_rows * a.density || a.num_cols > u32::MAX as usize {
+            return Err(GpuError::Shape("sparse matrix / vector shape mismatch".into()));
+        }
+        let ctx = self.gpu_ctx()?;
+        let n64 = self.n64();
+        let mut vals = vec![0u64; a.cells.len() * n64];
+        let mut cols = Vec::with_capacity(a.cells.len());
+        for ((c, v), chunk) in a.cells.iter().zip(vals.chunks_exact_mut(n64)) {
+            cols.push(u32::try_from(*c).map_err(|_| GpuError::Shape("column index beyond u32".into()))?);
+            self.write_words(v, chunk);
+        }
+        let xw = self.gather(x);
+        let mut yw = vec![0u64; a.num_rows * n64];
+        // Safety: vals / cols hold rows*density cells, x cols, y rows elements.
+        check(unsafe {
+            sys::fpgpu_spmv(ctx.ptr(), vals.as_ptr(), cols.as_ptr(), a.num_rows, a.num_cols, a.density, xw.as_ptr(), yw.as_mut_ptr())
+        })?;
+        Ok(self.scatter(&yw))
+    }
+    /// `C[i][j] = sum_refs_l mul(A[i][l], B[l][j])`.
+    fn matmul(&self, a: &DenseRowMatrix<Self::Element>, b: &DenseRowMatrix<Self::Element>)
+              -> Result<DenseRowMatrix<Self::Element>, GpuError> {
+        if a.num_cols != b.num_rows || a.data.len() != a.num_rows * a.num_cols || b.data.len() != b.num_rows * b.num_cols {
+            return Err(GpuError::Shape("matrix shapes do not chain".into()));
+        }
+        let ctx = self.gpu_ctx()?;
+        let (aw, bw) = (self.gather(&a.data), self.gather(&b.data));
+        let mut cw = vec![0u64; a.num_rows * b.num_cols * self.n64()];
+        // Safety: A is m x k, B is k x n, C is m x n elements.
+        check(unsafe {
+            sys::fpgpu_matmul(ctx.ptr(), aw.as_ptr(), bw.as_ptr(), cw.as_mut_ptr(), a.num_rows, a.num_cols, b.num_cols)
+        })?;
+        Ok(DenseRowMatrix { num_rows: a.num_rows, num_cols: b.num_cols, data: self.scatter(&cw) })
+    }
+}
+impl<T: GpuMarshal> BatchFieldConfig for T {}
+
+type Bin = unsafe extern "C" fn(*const sys::fpgpu_ctx, *const u64, *const u64, *mut u64, usize) -> i32;
+type Un = unsafe extern "C" fn(*const sys::fpgpu_ctx, *const u64, *mut u64, usize) -> i32;
+type Fold = unsafe extern "C" fn(*const sys::fpgpu_ctx, *const u64, usize, *mut u64) -> i32;
+
+fn binary<C: GpuMarshal + ?Sized>(c: &C, a: &[C::Element], b: &[C::Element], f: Bin) -> Result<Vec<C::Element>, GpuError> {
+    if a.len() != b.len() {
+        return Err(GpuError::Shape("operand lengths differ".into()));
+    }
+    let ctx = c.gpu_ctx()?;
+    let (aw, bw) = (c.gather(a), c.gather(b));
+    let mut ow = vec![0u64; aw.len()];
+    // Safety: the three buffers hold a.len() elements of n64 words.
+    check(unsafe { f(ctx.ptr(), aw.as_ptr(), bw.as_ptr(), ow.as_mut_ptr(), a.len()) })?;
+    Ok(c.scatter(&ow))
+}
+
+fn unary<C: GpuMarshal + ?Sized>(c: &C, a: &[C::Element], f: Un) -> Result<Vec<C::Element>, GpuError> {
+    let ctx = c.gpu_ctx()?;
+    let aw = c.gather(a);
+    let mut ow = vec![0u64; aw.len()];
+    // Safety: both buffers hold a.len() elements of n64 words.
+    check(unsafe { f(ctx.ptr(), aw.as_ptr(), ow.as_mut_ptr(), a.len()) })?;
+    Ok(c.scatter(&ow))
+}
+
+fn fold<C: GpuMarshal + ?Sized>(c: &C, v: &[C::Element], f: Fold) -> Result<C::Element, GpuError> {
+    let ctx = c.gpu_ctx()?;
+    let vw = c.gather(v);
+    let mut ow = vec![0u64; c.n64()];
+    // Safety: `vw` holds v.len() elements, `ow` one.
+    check(unsafe { f(ctx.ptr(), vw.as_ptr(), v.len(), ow.as_mut_ptr()) })?;
+    Ok(c.read_words(&ow))
+}
+
+// ---- MontyField<LIMBS> (src/field/crypto_bigint_monty.rs:16-58): runtime modulus, stack limbs
+impl<const LIMBS: usize> GpuMarshal for MontyField<LIMBS> {
+    fn n64(&self) -> usize {
+        LIMBS
+    }
+    fn modulus_words(&self) -> Vec<u64> {
+        self.modulus().as_words().to_vec() // BaseFieldConfig::modulus, :355-357
+    }
+    fn write_words(&self, e: &MontyFieldElement<LIMBS>, out: &mut [u64]) {
+        out.copy_from_slice(e.0.as_words()); // the Montgomery representative (:56-58)
+    }
+    fn read_words(&self, words: &[u64]) -> MontyFieldElement<LIMBS> {
+        let mut w = [0u64; LIMBS];
+        w.copy_from_slice(words);
+        MontyFieldElement(Uint::from_words(w))
+    }
+    fn integer_words(&self, e: &Uint<LIMBS>) -> Vec<u64> {
+        e.as_words().to_vec()
+    }
+}
+
+// ---- BoxedMontyField (src/field/crypto_bigint_boxed_monty.rs:18-64): heap limbs, one
+// allocation per element, so the adapter gathers them into one contiguous buffer.
+impl GpuMarshal for BoxedMontyField {
+    fn n64(&self) -> usize {
+        (self.bits_precision() / 64) as usize // R = 2^bits_precision (:55-57)
+    }
+    fn modulus_words(&self) -> Vec<u64> {
+        self.modulus().as_words().to_vec()
+    }
+    fn write_words(&self, e: &BoxedMontyFieldElement, out: &mut [u64]) {
+        out.copy_from_slice(e.0.as_words());
+    }
+    fn read_words(&self, words: &[u64]) -> BoxedMontyFieldElement {
+        let mut v = BoxedUint::new(crypto_bigint::BoxedUint::zero_with_precision(self.bits_precision()));
+        v.as_mut_words().copy_from_slice(words);
+        BoxedMontyFieldElement(v)
+    }
+    fn integer_words(&self, e: &BoxedUint) -> Vec<u64> {
+        e.as_words().to_vec()
+    }
+}
+
+// ---- FixedConfig<ConstMontyField<Mod, LIMBS>> (src/lib.rs:78-89,
+// src/field/crypto_bigint_const_monty.rs:27-31): compile-time modulus
+impl<Mod: ConstMontyParams<LIMBS>, const LIMBS: usize> GpuMarshal for FixedConfig<ConstMontyField<Mod, LIMBS>>
+where
+    FixedConfig<ConstMontyField<Mod, LIMBS>>: FieldConfig<Element = ConstMontyField<Mod, LIMBS>, Integer = Uint<LIMBS>>,
+{
+    fn n64(&self) -> usize {
+        LIMBS
+    }
+    fn modulus_words(&self) -> Vec<u64> {
+        Mod::PARAMS.modulus().as_ref().as_words().to_vec()
+    }
+    fn write_words(&self, e: &ConstMontyField<Mod, LIMBS>, out: &mut [u64]) {
+        out.copy_from_slice(e.as_montgomery().as_words()); // :61-64
+    }
+    fn read_words(&self, words: &[u64]) -> ConstMontyField<Mod, LIMBS> {
+        let mut w = [0u64; LIMBS];
+        w.copy_from_slice(words);
+        ConstMontyField::from_montgomery(Uint::from_words(w)) // :71-74
+    }
+    fn integer_words(&self, e: &Uint<LIMBS>) -> Vec<u64> {
+        e.as_words().to_vec()
+    }
+}
+
+/// `BaseFieldConfig::new` with the modulus check done by the library: an even modulus is
+/// rejected by both sides with `InvalidModulus` (crypto_bigint_monty.rs:346-352).
+pub fn monty_field_with_gpu<const LIMBS: usize>(modulus: &Uint<LIMBS>) -> Result<(MontyField<LIMBS>, GpuCtx), FieldError> {
+    let ctx = GpuCtx::new(modulus.as_words())?;
+    Ok((MontyField::<LIMBS>::new(modulus)?, ctx))
+}
+
+#[cfg(test)]
+mod tests {
+    //! The reference's own test shapes (known answers on secp256k1's prime,
+    //! crypto_bigint_monty.rs:564-592; inv(0) = None, :778-780), through the batch methods,
+    //! against the scalar methods of the same config.  Needs an MI355X.
+    use super::*;
+    use crypto_primitives::{ProjectElementWithConfig, RingConfig, SemiringConfig};
+
+    fn field() -> MontyField<4> {
+        let p = Uint::<4>::from_words([0xFFFFFFFEFFFFFC2F, u64::MAX, u64::MAX, u64::MAX]); // 2^256 - 2^32 - 977
+        MontyField::<4>::new(&p).unwrap()
+    }
+
+    #[test]
+    fn batch_equals_scalar() {
+        let f = field();
+        let a: Vec<_> = (1u64..200).map(|v| f.project(&(v * 0x9E3779B97F4A7C15))).collect();
+        let b: Vec<_> = (1u64..200).map(|v| f.project(&(v * 0xBF58476D1CE4E5B9))).collect();
+        let mul = f.mul_batch(&a, &b).unwrap();
+        let add = f.add_batch(&a, &b).unwrap();
+        let sub = f.sub_batch(&a, &b).unwrap();
+        let neg = f.neg_batch(&a).unwrap();
+        for i in 0..a.len() {
+            assert_eq!(mul[i], f.mul(&a[i], &b[i]));
+            assert_eq!(add[i], f.add(&a[i], &b[i]));
+            assert_eq!(sub[i], f.sub(&a[i], &b[i]));
+            assert_eq!(neg[i], f.neg(&a[i]));
+        }
+        assert_eq!(f.sum_batch(&a).unwrap(), f.sum_refs(a.iter()));
+        assert_eq!(f.product_batch(&a).unwrap(), f.product_refs(a.iter()));
+    }
+
+    #[test]
+    fn inversion_and_zero() {
+        let f = field();
+        let mut x: Vec<_> = (1u64..100).map(|v| f.project(&v)).collect();
+        x[7] = f.zero();
+        let inv = f.inv_batch(&x).unwrap();
+        for (i, v) in x.iter().enumerate() {
+            assert_eq!(inv[i], f.inv(v));
+        }
+        assert!(inv[7].is_none());
+    }
+
+    #[test]
+    #[should_panic(expected = "Division by zero")]
+    fn division_by_zero_panics() {
+        let f = field();
+        let _ = f.div_batch(&[f.one()], &[f.zero()]);
+    }
+
+    #[test]
+    fn even_modulus_rejected() {
+        assert_eq!(GpuCtx::new(&[42, 0, 0, 0]).err(), Some(GpuError::InvalidModulus));
+    }
+}

@@ -1,0 +1,97 @@
+//! Raw bindings to `include/fpgpu.h`, one item per declaration, in the header's order.
+//! Element layout everywhere: element `i` = `n64` little-endian `u64` words at index `i * n64`
+//! (`Uint::as_words()`, src/semiring/crypto_bigint_uint.rs:65-68), Montgomery form, R = 2^(64 n64).
+#![no_std]
+#![allow(non_camel_case_types)]
+
+use core::ffi::{c_char, c_int, c_void};
+
+/// Opaque `fpgpu_ctx`: immutable after creation, shareable between threads.
+#[repr(C)]
+pub struct fpgpu_ctx {
+    _private: [u8; 0],
+}
+
+pub const FPGPU_OK: c_int = 0;
+/// Even or zero modulus: `FieldError::InvalidModulus` (src/field.rs:345-349).
+pub const FPGPU_ERR_INVALID_MODULUS: c_int = 1;
+pub const FPGPU_ERR_UNSUPPORTED: c_int = 2;
+pub const FPGPU_ERR_SHAPE: c_int = 3;
+pub const FPGPU_ERR_HIP: c_int = 4;
+/// No gfx950 device visible: there is no CPU fallback.
+pub const FPGPU_ERR_NO_DEVICE: c_int = 5;
+pub const FPGPU_MAX_N64: u32 = 8;
+
+extern "C" {
+    // ---- field configuration
+    pub fn fpgpu_ctx_create(modulus_le: *const u64, n64: u32, out: *mut *mut fpgpu_ctx) -> c_int;
+    pub fn fpgpu_ctx_destroy(ctx: *mut fpgpu_ctx);
+    pub fn fpgpu_ctx_n64(ctx: *const fpgpu_ctx) -> u32;
+    pub fn fpgpu_ctx_params(ctx: *const fpgpu_ctx, modulus_le: *mut u64, one_le: *mut u64, r2_le: *mut u64,
+                            mod_neg_inv: *mut u64) -> c_int;
+
+    // ---- elementwise batches, device buffers (asynchronous on `stream`, a hipStream_t)
+    pub fn fpgpu_mul_dev(ctx: *const fpgpu_ctx, a: *const c_void, b: *const c_void, out: *mut c_void, n: usize,
+                         stream: *mut c_void) -> c_int;
+    pub fn fpgpu_sqr_dev(ctx: *const fpgpu_ctx, a: *const c_void, out: *mut c_void, n: usize, stream: *mut c_void) -> c_int;
+    pub fn fpgpu_add_dev(ctx: *const fpgpu_ctx, a: *const c_void, b: *const c_void, out: *mut c_void, n: usize,
+                         stream: *mut c_void) -> c_int;
+    pub fn fpgpu_sub_dev(ctx: *const fpgpu_ctx, a: *const c_void, b: *const c_void, out: *mut c_void, n: usize,
+                         stream: *mut c_void) -> c_int;
+    pub fn fpgpu_neg_dev(ctx: *const fpgpu_ctx, a: *const c_void, out: *mut c_void, n: usize, stream: *mut c_void) -> c_int;
+    pub fn fpgpu_to_mont_dev(ctx: *const fpgpu_ctx, a: *const c_void, out: *mut c_void, n: usize, stream: *mut c_void) -> c_int;
+    pub fn fpgpu_from_mont_dev(ctx: *const fpgpu_ctx, a: *const c_void, out: *mut c_void, n: usize, stream: *mut c_void) -> c_int;
+    pub fn fpgpu_mul_chain_dev(ctx: *const fpgpu_ctx, a: *const c_void, b: *const c_void, out: *mut c_void, n: usize,
+                               iters: u32, stream: *mut c_void) -> c_int;
+
+    // ---- pow, folds
+    pub fn fpgpu_pow_dev(ctx: *const fpgpu_ctx, a: *const c_void, exponent_le: *const u64, exponent_words: u32,
+                         out: *mut c_void, n: usize, stream: *mut c_void) -> c_int;
+    pub fn fpgpu_fold_workspace_bytes(ctx: *const fpgpu_ctx) -> usize;
+    pub fn fpgpu_sum_dev(ctx: *const fpgpu_ctx, v: *const c_void, n: usize, out: *mut c_void, workspace: *mut c_void,
+                         workspace_bytes: usize, stream: *mut c_void) -> c_int;
+    pub fn fpgpu_product_dev(ctx: *const fpgpu_ctx, v: *const c_void, n: usize, out: *mut c_void, workspace: *mut c_void,
+                             workspace_bytes: usize, stream: *mut c_void) -> c_int;
+
+    // ---- batch inversion
+    pub fn fpgpu_batch_inv_workspace_bytes(ctx: *const fpgpu_ctx, n: usize) -> usize;
+    pub fn fpgpu_batch_inv_dev(ctx: *const fpgpu_ctx, x: *const c_void, out: *mut c_void, zero_flags: *mut u8, n: usize,
+                               workspace: *mut c_void, workspace_bytes: usize, stream: *mut c_void) -> c_int;
+
+    // ---- matrix products
+    pub fn fpgpu_matvec_workspace_bytes(ctx: *const fpgpu_ctx, rows: usize, cols: usize) -> usize;
+    pub fn fpgpu_matvec_dev(ctx: *const fpgpu_ctx, a: *const c_void, rows: usize, cols: usize, x: *const c_void,
+                            y: *mut c_void, workspace: *mut c_void, workspace_bytes: usize, stream: *mut c_void) -> c_int;
+    pub fn fpgpu_spmv_dev(ctx: *const fpgpu_ctx, vals: *const c_void, col_idx: *const u32, rows: usize, cols: usize,
+                          density: usize, x: *const c_void, y: *mut c_void, stream: *mut c_void) -> c_int;
+    pub fn fpgpu_matmul_workspace_bytes(ctx: *const fpgpu_ctx, m: usize, k: usize, n: usize) -> usize;
+    pub fn fpgpu_matmul_dev(ctx: *const fpgpu_ctx, a: *const c_void, b: *const c_void, c: *mut c_void, m: usize, k: usize,
+                            n: usize, workspace: *mut c_void, workspace_bytes: usize, stream: *mut c_void) -> c_int;
+
+    // ---- synthetic inputs
+    pub fn fpgpu_fill_random_dev(ctx: *const fpgpu_ctx, out: *mut c_void, n: usize, seed: u64, stream: *mut c_void) -> c_int;
+
+    // ---- host-buffer calls (synchronous: H2D, kernel, D2H)
+    pub fn fpgpu_mul(ctx: *const fpgpu_ctx, a: *const u64, b: *const u64, out: *mut u64, n: usize) -> c_int;
+    pub fn fpgpu_sqr(ctx: *const fpgpu_ctx, a: *const u64, out: *mut u64, n: usize) -> c_int;
+    pub fn fpgpu_add(ctx: *const fpgpu_ctx, a: *const u64, b: *const u64, out: *mut u64, n: usize) -> c_int;
+    pub fn fpgpu_sub(ctx: *const fpgpu_ctx, a: *const u64, b: *const u64, out: *mut u64, n: usize) -> c_int;
+    pub fn fpgpu_neg(ctx: *const fpgpu_ctx, a: *const u64, out: *mut u64, n: usize) -> c_int;
+    pub fn fpgpu_to_mont(ctx: *const fpgpu_ctx, a: *const u64, out: *mut u64, n: usize) -> c_int;
+    pub fn fpgpu_from_mont(ctx: *const fpgpu_ctx, a: *const u64, out: *mut u64, n: usize) -> c_int;
+    pub fn fpgpu_mul_chain(ctx: *const fpgpu_ctx, a: *const u64, b: *const u64, out: *mut u64, n: usize, iters: u32) -> c_int;
+    pub fn fpgpu_pow(ctx: *const fpgpu_ctx, a: *const u64, exponent_le: *const u64, exponent_words: u32, out: *mut u64,
+                     n: usize) -> c_int;
+    pub fn fpgpu_sum(ctx: *const fpgpu_ctx, v: *const u64, n: usize, out: *mut u64) -> c_int;
+    pub fn fpgpu_product(ctx: *const fpgpu_ctx, v: *const u64, n: usize, out: *mut u64) -> c_int;
+    pub fn fpgpu_batch_inv(ctx: *const fpgpu_ctx, x: *const u64, out: *mut u64, zero_flags: *mut u8, n: usize) -> c_int;
+    pub fn fpgpu_matvec(ctx: *const fpgpu_ctx, a: *const u64, rows: usize, cols: usize, x: *const u64, y: *mut u64) -> c_int;
+    pub fn fpgpu_spmv(ctx: *const fpgpu_ctx, vals: *const u64, col_idx: *const u32, rows: usize, cols: usize,
+                      density: usize, x: *const u64, y: *mut u64) -> c_int;
+    pub fn fpgpu_matmul(ctx: *const fpgpu_ctx, a: *const u64, b: *const u64, c: *mut u64, m: usize, k: usize, n: usize) -> c_int;
+
+    // ---- diagnostics
+    pub fn fpgpu_last_error_string() -> *const c_char;
+    pub fn fpgpu_device_count() -> c_int;
+    pub fn fpgpu_version() -> *const c_char;
+}
