@@ -77,3 +77,21 @@ def test_no_cpu_fallback_without_gpu():
     assert e.value.code == _lib.ERR_NO_DEVICE
     with pytest.raises(cpa.FpgpuError):
         f.inv(a)
+
+
+def test_rust_sys_crate_binds_every_declared_symbol():
+    """rust/fpgpu-sys cannot be compiled in this image (no cargo); at least keep its extern block
+    in step with the header: same set of functions, same argument counts."""
+    hdr = open(os.path.join(ROOT, "include", "fpgpu.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    rs = open(os.path.join(ROOT, "rust", "fpgpu-sys", "src", "lib.rs")).read()
+    rs = re.sub(r"//.*", "", rs)
+    c_decl = {m.group(1): m.group(2) for m in re.finditer(r"\b(fpgpu_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", hdr)}
+    r_decl = {m.group(1): m.group(2) for m in re.finditer(r"pub fn (fpgpu_[a-z0-9_]+)\s*\(([^)]*)\)", rs)}
+    assert sorted(c_decl) == sorted(r_decl)
+
+    def nargs(a):
+        a = a.strip()
+        return 0 if a in ("", "void") else a.count(",") + 1
+    for name in c_decl:
+        assert nargs(c_decl[name]) == nargs(r_decl[name]), name
