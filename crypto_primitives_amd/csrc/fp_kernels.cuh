@@ -552,10 +552,13 @@ __global__ __launch_bounds__(kBlock) void k_spmv(const uint32_t* __restrict__ va
     }
 }
 
-// ---- dense mat-mul: C = A (m x k) * B (k x n), LDS-tiled -------------------------
-// 16 x 16 outputs per workgroup, one per lane; K walked in 16-wide tiles staged in
-// LDS.  First correct version; the register-tiled lazy-reduction variant for the
-// single-limb case replaces it in a later round.
+// ---- dense mat-mul: C = A (m x k) * B (k x n), LDS-tiled, multi-limb -----------------
+// 16 x 16 outputs per workgroup, one per lane; K walked in 16-wide tiles staged in LDS.
+// Lazy reduction as in k_matvec: every term adds its plain 2N-limb product (N^2 multiplies)
+// into a per-output 2N-limb accumulator kept below p*R (wide_acc_add), and the N^2 + N
+// multiplies of the Montgomery reduction are paid once per output (mont_redc_wide), not once per
+// term.  The canonical residue of (sum of a*b) * R^-1 is the reference's fold of mul and add.
+// (Single-limb fields take k_matmul_mfma_1limb / k_matmul_1limb instead.)
 template <int N>
 __global__ __launch_bounds__(kMMTile* kMMTile) void k_matmul(const uint32_t* __restrict__ A,
                                                              const uint32_t* __restrict__ B,
@@ -566,9 +569,9 @@ __global__ __launch_bounds__(kMMTile* kMMTile) void k_matmul(const uint32_t* __r
     const int tx = threadIdx.x % kMMTile, ty = threadIdx.x / kMMTile;
     const size_t row = (size_t)blockIdx.y * kMMTile + ty;
     const size_t col = (size_t)blockIdx.x * kMMTile + tx;
-    uint32_t acc[N];
+    uint32_t S[2 * N];
 #pragma unroll
-    for (int l = 0; l < N; l++) acc[l] = 0;
+    for (int l = 0; l < 2 * N; l++) S[l] = 0;
     for (size_t k0 = 0; k0 < k; k0 += kMMTile) {
         uint32_t v[N];
         if (row < m && k0 + tx < k) load_elem<N>(v, A, row * k + k0 + tx);
@@ -588,16 +591,16 @@ __global__ __launch_bounds__(kMMTile* kMMTile) void k_matmul(const uint32_t* __r
         __syncthreads();
 #pragma unroll 1
         for (int kk = 0; kk < kMMTile; kk++) {
-            uint32_t a[N], b[N], pr[N], s[N];
+            uint32_t a[1][N], b[1][N], prod[2 * N];
 #pragma unroll
-            for (int l = 0; l < N; l++) { a[l] = sA[ty][kk][l]; b[l] = sB[kk][tx][l]; }
-            mont_mul<N>(pr, a, b, P);
-            mod_add<N>(s, acc, pr, P);
-#pragma unroll
-            for (int l = 0; l < N; l++) acc[l] = s[l];
+            for (int l = 0; l < N; l++) { a[0][l] = sA[ty][kk][l]; b[0][l] = sB[kk][tx][l]; }
+            mul_wide_sum<N, 1>(prod, a, b);
+            wide_acc_add<N>(S, prod, P);
         }
         __syncthreads();
     }
+    uint32_t acc[N];
+    mont_redc_wide<N>(acc, S, P);
     if (row < m && col < n) store_elem<N>(Cm, row * n + col, acc);
 }
 
