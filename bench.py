@@ -194,6 +194,7 @@ def main():
             extra["matmul_goldilocks"] = bench_matmul(args, world, rank, distributed, time_steps, primary=False)
         if args.workload != "matvec":
             extra["matvec_bn254"] = bench_matvec(args, f, world, rank, distributed, time_steps, primary=False)
+        extra["spmv_bn254"] = bench_spmv(f, rank, time_steps)
 
     # ---------------- CPU baseline (rank 0, N = 1 only) --------------------------------
     cpu = None
@@ -332,6 +333,24 @@ def bench_matvec(args, f, world, rank, distributed, time_steps, primary):
                             "kernel": "k_matvec_mfma<8,4> (+ k_mv_expand, k_mv_finish)"},
                "verified_vs_oracle": None}
     return res
+
+
+def bench_spmv(f, rank, time_steps):
+    """SparseMatrix mat-vec, one replica per rank: 2^20 rows x 32 cells per row over
+    2^20 columns, BN254 Fr; uniform random columns, so x is gathered through L2 / Infinity Cache."""
+    import torch
+    rows = cols = 1 << 20
+    density = 32
+    vals = f.random_dev(rows * density, 0x5A ^ (17 + 1000 * rank))
+    x = f.random_dev(cols, 0x5B)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(1234 + rank)
+    col = torch.randint(0, cols, (rows * density,), dtype=torch.int32, device="cuda", generator=g)
+    y = f.alloc(rows)
+    wall, kern = time_steps(lambda: f.spmv_dev(vals, col, rows, cols, density, x, y), 5, 1)
+    bytes_alg = 36.0 * rows * density + 32.0 * (cols + rows)   # value + index per cell, x and y once
+    return {"cells_per_s": rows * density / kern, "ms": kern * 1e3, "rows": rows, "density": density,
+            "hbm_GBps_per_gpu": bytes_alg / kern / 1e9, "hbm_frac": bytes_alg / kern / 1e9 / HBM_PEAK_GBPS}
 
 
 def _pmc_traffic(workload, key, value):

@@ -508,8 +508,7 @@ __global__ __launch_bounds__(kBlock) void k_matvec(const uint32_t* __restrict__ 
 // ---- sparse mat-vec over SparseMatrix<T> (src/matrix.rs:46-61: `density`
 // cells (column index, value) per row, rows stored back to back) -----------------------
 // y[i] = sum_{j < density} mul(val[i*density + j], x[col[i*density + j]]): the same fold of mul and
-// add as the dense product.  G = 2^log2g lanes share a row (G is the power of two covering the
-// density, at most 64): values are read coalesced, x is gathered, products are accumulated
+// add as the dense product.  G = 2^log2g lanes share a row (chosen by the launcher, at most 64): values are read coalesced, x is gathered, products are accumulated
 // lazily per lane (as k_matvec) and the G partial residues are summed with a butterfly.
 // A column index >= cols contributes nothing (the host entry point rejects such input).
 template <int N>

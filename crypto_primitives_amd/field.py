@@ -242,6 +242,17 @@ class MontyField:
                                          self._stream()))
         return y
 
+    def spmv_dev(self, vals, col_idx, rows, cols, density, x, y):
+        """SparseMatrix (fixed `density` cells per row) times vector on device tensors; col_idx is a
+        contiguous 4-byte integer CUDA tensor of rows*density column indices (< cols)."""
+        if not col_idx.is_cuda or not col_idx.is_contiguous() or col_idx.element_size() != 4 or col_idx.numel() != rows * density:
+            raise ValueError("expected a contiguous CUDA tensor of rows*density 4-byte column indices")
+        if vals.shape[0] != rows * density or x.shape[0] != cols or y.shape[0] != rows:
+            raise ValueError("sparse matrix / vector shape mismatch")
+        check(self._lib.fpgpu_spmv_dev(self._h, self._chk_t(vals), ctypes.c_void_p(col_idx.data_ptr()), rows, cols, density,
+                                       self._chk_t(x), self._chk_t(y), self._stream()))
+        return y
+
     def matmul_workspace_bytes(self, m, k, n):
         return int(self._lib.fpgpu_matmul_workspace_bytes(self._h, m, k, n))
 
