@@ -552,54 +552,94 @@ __global__ __launch_bounds__(kBlock) void k_spmv(const uint32_t* __restrict__ va
 }
 
 // ---- dense mat-mul: C = A (m x k) * B (k x n), LDS-tiled, multi-limb -----------------
-// 16 x 16 outputs per workgroup, one per lane; K walked in 16-wide tiles staged in LDS.
-// Lazy reduction as in k_matvec: every term adds its plain 2N-limb product (N^2 multiplies)
-// into a per-output 2N-limb accumulator kept below p*R (wide_acc_add), and the N^2 + N
-// multiplies of the Montgomery reduction are paid once per output (mont_redc_wide), not once per
-// term.  The canonical residue of (sum of a*b) * R^-1 is the reference's fold of mul and add.
+// 16 x 16 outputs per workgroup, one per lane; K walked in 16-wide tiles staged in LDS as
+// unsaturated 29-bit limbs (fp_unsat.cuh: L limbs per element, converted once per tile element).
+// A term is L^2 v_mad_u64_u32 into 2L - 1 independent 64-bit COLUMN sums that live across terms:
+// a limb product is < 2^58, so a column takes T * L of them before it must be normalised (carry
+// = column >> 29 into the next column); no carry instruction, no shift and no reduction inside a
+// term (81 multiplies per 256-bit term against 64 + 64 carry adds + a wide add before).  The exact
+// integer V = sum of a*b is rebuilt once per output and reduced with three Montgomery
+// multiplications, V = W0 + W1 R + W2 R^2  =>  V R^-1 = mont(W0, 1) + mont(W1, R) + mont(W2, R^2)
+// (mod p): the canonical residue, i.e. the reference's fold of mul and add, for any a, b < R.
 // (Single-limb fields take k_matmul_mfma_1limb / k_matmul_1limb instead.)
+template <int L>
+struct MMTerms {   // terms a column may absorb between normalisations: T * L + 1 <= 64, T | 16
+    static constexpr int T = 63 / L >= 16 ? 16 : (63 / L >= 8 ? 8 : (63 / L >= 4 ? 4 : (63 / L >= 2 ? 2 : 1)));
+};
 template <int N>
 __global__ __launch_bounds__(kMMTile* kMMTile) void k_matmul(const uint32_t* __restrict__ A,
                                                              const uint32_t* __restrict__ B,
                                                              uint32_t* __restrict__ Cm, size_t m, size_t k, size_t n,
                                                              const FpParams<N> P) {
-    __shared__ uint32_t sA[kMMTile][kMMTile][N];
-    __shared__ uint32_t sB[kMMTile][kMMTile][N];
+    constexpr int L = UF<N>::L, NC = 2 * L + 2, T = MMTerms<L>::T;
+    constexpr uint32_t M = UF<N>::C::MASK;
+    __shared__ uint32_t sA[kMMTile][kMMTile][L];
+    __shared__ uint32_t sB[kMMTile][kMMTile][L];
     const int tx = threadIdx.x % kMMTile, ty = threadIdx.x / kMMTile;
     const size_t row = (size_t)blockIdx.y * kMMTile + ty;
     const size_t col = (size_t)blockIdx.x * kMMTile + tx;
-    uint32_t S[2 * N];
+    uint64_t c[NC];   // column sums; c[2L-1 ..] only receive carries
 #pragma unroll
-    for (int l = 0; l < 2 * N; l++) S[l] = 0;
+    for (int i = 0; i < NC; i++) c[i] = 0;
+    auto normalise = [&]() {
+#pragma unroll
+        for (int i = 0; i + 1 < NC; i++) {
+            c[i + 1] += c[i] >> kUB;
+            c[i] &= M;
+        }
+    };
     for (size_t k0 = 0; k0 < k; k0 += kMMTile) {
-        uint32_t v[N];
+        uint32_t v[N], lv[L];
         if (row < m && k0 + tx < k) load_elem<N>(v, A, row * k + k0 + tx);
         else {
 #pragma unroll
             for (int l = 0; l < N; l++) v[l] = 0;
         }
+        uload<N>(lv, v);
 #pragma unroll
-        for (int l = 0; l < N; l++) sA[ty][tx][l] = v[l];
+        for (int l = 0; l < L; l++) sA[ty][tx][l] = lv[l];
         if (k0 + ty < k && col < n) load_elem<N>(v, B, (k0 + ty) * n + col);
         else {
 #pragma unroll
             for (int l = 0; l < N; l++) v[l] = 0;
         }
+        uload<N>(lv, v);
 #pragma unroll
-        for (int l = 0; l < N; l++) sB[ty][tx][l] = v[l];
+        for (int l = 0; l < L; l++) sB[ty][tx][l] = lv[l];
         __syncthreads();
 #pragma unroll 1
-        for (int kk = 0; kk < kMMTile; kk++) {
-            uint32_t a[1][N], b[1][N], prod[2 * N];
+        for (int kk = 0; kk < kMMTile; kk += T) {
 #pragma unroll
-            for (int l = 0; l < N; l++) { a[0][l] = sA[ty][kk][l]; b[0][l] = sB[kk][tx][l]; }
-            mul_wide_sum<N, 1>(prod, a, b);
-            wide_acc_add<N>(S, prod, P);
+            for (int t = 0; t < T; t++) {
+                uint32_t a[L], b[L];
+#pragma unroll
+                for (int l = 0; l < L; l++) { a[l] = sA[ty][kk + t][l]; b[l] = sB[kk + t][tx][l]; }
+#pragma unroll
+                for (int i = 0; i < L; i++)
+#pragma unroll
+                    for (int j = 0; j < L; j++) c[i + j] += (uint64_t)a[i] * b[j];
+            }
+            normalise();
         }
         __syncthreads();
     }
-    uint32_t acc[N];
-    mont_redc_wide<N>(acc, S, P);
+    // the top column has absorbed every carry: spread it over the spare limbs, then all limbs are < 2^29
+    normalise();
+    normalise();
+    uint32_t limbs[NC], w[3 * N];
+#pragma unroll
+    for (int i = 0; i < NC; i++) limbs[i] = (uint32_t)c[i];
+    from_limbs<3 * N, kUB, NC>(w, limbs);   // V < k * R^2 < 2^(64 N + 64): words beyond that are zero
+    uint32_t w0[N], w1[N], w2[N], one[N], r1[N], r2[N], t0[N], t1[N], t2[N], s[N], acc[N];
+#pragma unroll
+    for (int l = 0; l < N; l++) { w0[l] = w[l]; w1[l] = w[N + l]; w2[l] = w[2 * N + l]; one[l] = l == 0 ? 1u : 0u; }
+    set_limbs<N>(r1, P.one);
+    set_limbs<N>(r2, P.r2);
+    mont_mul<N>(t0, w0, one, P);
+    mont_mul<N>(t1, w1, r1, P);
+    mont_mul<N>(t2, w2, r2, P);
+    mod_add<N>(s, t0, t1, P);
+    mod_add<N>(acc, s, t2, P);
     if (row < m && col < n) store_elem<N>(Cm, row * n + col, acc);
 }
 

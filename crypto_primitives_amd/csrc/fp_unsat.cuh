@@ -59,13 +59,13 @@ __device__ __forceinline__ void to_limbs(uint32_t (&l)[L], const uint32_t (&w)[N
     }
 }
 
-// words of the value held in normalised limbs (every limb < 2^B); the value must be < 2^(32*NW)
+// words of the value held in L normalised limbs (every limb < 2^B); the value must be < 2^(32*NW)
 template <int NW, int B, int L = UCfg<NW, B>::L>
 __device__ __forceinline__ void from_limbs(uint32_t (&w)[NW], const uint32_t (&l)[L]) {
 #pragma unroll
     for (int j = 0; j < NW; j++) {
         const int i0 = (32 * j) / B, s = 32 * j - i0 * B;  // word j starts s bits into limb i0
-        uint32_t v = l[i0] >> s;
+        uint32_t v = i0 < L ? l[i0] >> s : 0u;   // words beyond the limbs are zero
         if (i0 + 1 < L) v |= l[i0 + 1] << (B - s);
         if (2 * B - s < 32 && i0 + 2 < L) v |= l[i0 + 2] << (2 * B - s);
         w[j] = v;

@@ -617,3 +617,18 @@ def test_batch_inv_composite_modulus_wide(cpa):
     want, wflags = o.batch_inv(x)
     assert np.array_equal(flags, wflags) and np.array_equal(got, want)
     assert flags.sum() >= 4
+
+
+@pytest.mark.parametrize("case", _UNSAT_MODULI, ids=[c[0] for c in _UNSAT_MODULI])
+def test_matmul_multi_limb_every_width(cpa, case):
+    """Multi-limb mat-mul (column sums on unsaturated limbs carried across terms, one exact
+    reduction per output) at every compiled width, ragged shapes, K beyond one LDS tile, and
+    operands at the top of the range."""
+    from oracle.fp_oracle import Oracle
+    _, p, n64 = case
+    f, o = cpa.MontyField(p, n64), Oracle(p, n64)
+    rnd = random.Random(n64)
+    for m, k, n in ((1, 1, 1), (3, 17, 5), (20, 100, 18), (2, 1000, 3)):
+        A = ints_to_array([rnd.choice((p - 1, p - 2, rnd.randrange(p))) for _ in range(m * k)], n64)
+        B = ints_to_array([rnd.choice((p - 1, 1, rnd.randrange(p))) for _ in range(k * n)], n64)
+        assert np.array_equal(f.matmul(A, B, m, k, n), o.matmul(A, B, m, k, n, threads=0)), (m, k, n)
