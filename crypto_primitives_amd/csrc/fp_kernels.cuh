@@ -658,22 +658,20 @@ template <int N>
 __global__ __launch_bounds__(kBlock) void k_pow(const uint32_t* __restrict__ a, uint32_t* __restrict__ out, size_t n,
                                                 const PowExp e, const FpParams<N> P) {
     const size_t stride = (size_t)gridDim.x * kBlock;
-    Chain<N> acc(P);   // fp_unsat.cuh: unsaturated limbs from N = 6 on, lazily reduced where the modulus allows
+    PowLadder<N> ladder(P);   // fp_unsat.cuh: from N = 6 on, unsaturated limbs in the domain of R' = 2^(29 L)
     for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
         uint32_t w[N];
         if (e.top < 0) {
             set_limbs<N>(w, P.one);
         } else {
-            typename Chain<N>::Op x;
             load_elem<N>(w, a, i);
             if (e.top > 0) {   // exponent one hands the input back untouched
-                Chain<N>::prep(x, w);
-                acc.set(w);
+                ladder.start(w);
                 for (int b = e.top - 1; b >= 0; b--) {
-                    acc.square();
-                    if ((e.w[b >> 5] >> (b & 31)) & 1u) acc.mul_op(x);
+                    ladder.square();
+                    if ((e.w[b >> 5] >> (b & 31)) & 1u) ladder.mul_base();
                 }
-                acc.get_canonical(w);
+                ladder.finish(w);
             }
         }
         store_elem<N>(out, i, w);

@@ -141,6 +141,53 @@ __device__ __forceinline__ void umont_mul(uint32_t (&r)[L], const uint32_t (&a)[
     r[L - 1] = (uint32_t)acc;
 }
 
+// Column K of the product-scanning Montgomery SQUARING: a_i a_j with i < j taken once against the
+// doubled limb d_j = 2 a_j (30 bits, product < 2^59), the diagonal a_i^2 as it is; L (L + 1) / 2
+// products instead of L^2.  Column bound: ceil(L / 2) * 2^59 + 2^58 + L * 2^58 <= (2L + 1) * 2^58,
+// as for the multiplication.
+template <int B, int L, int K>
+struct USqrCol {
+    static __device__ __forceinline__ void run(uint64_t& acc, const uint32_t (&a)[L], const uint32_t (&d)[L],
+                                               uint32_t (&u)[L], uint32_t (&r)[L], const UParams<L>& P) {
+        constexpr uint32_t M = (1u << B) - 1;
+        constexpr int I0 = K < L ? 0 : K - L + 1;             // first index of the column
+        constexpr int NP = (K - 1) / 2 - I0 + 1 > 0 && K > 0 ? (K - 1) / 2 - I0 + 1 : 0;   // pairs i < j
+        constexpr int A = NP + (K % 2 == 0 ? 1 : 0);
+        uint32_t x[A], y[A];
+#pragma unroll
+        for (int t = 0; t < NP; t++) { x[t] = a[I0 + t]; y[t] = d[K - I0 - t]; }
+        if constexpr (K % 2 == 0) { x[NP] = a[K / 2]; y[NP] = a[K / 2]; }
+        if constexpr (K < L) {
+            uint32_t q[K + 1];
+#pragma unroll
+            for (int i = 0; i <= K; i++) q[i] = P.p[K - i];
+            mad_column<A, K>(acc, x, y, u, q);
+            u[K] = ((uint32_t)acc * P.n0inv) & M;
+            acc += (uint64_t)u[K] * P.p[0];
+            acc_shr(acc, B);
+        } else {
+            constexpr int C = 2 * L - 1 - K;
+            uint32_t q[C];
+#pragma unroll
+            for (int i = 0; i < C; i++) q[i] = P.p[L - 1 - i];
+            mad_column<A, C>(acc, x, y, u + I0, q);
+            r[K - L] = (uint32_t)acc & M;
+            acc_shr(acc, B);
+        }
+        if constexpr (K + 1 < 2 * L - 1) USqrCol<B, L, K + 1>::run(acc, a, d, u, r, P);
+    }
+};
+// r = a * a / 2^(B*L) mod p, r < a*a/2^(B*L) + p, limbs of r normalised.
+template <int B, int L>
+__device__ __forceinline__ void umont_sqr(uint32_t (&r)[L], const uint32_t (&a)[L], const UParams<L>& P) {
+    uint32_t u[L], d[L];
+#pragma unroll
+    for (int i = 0; i < L; i++) d[i] = a[i] << 1;
+    uint64_t acc = 0;
+    USqrCol<B, L, 0>::run(acc, a, d, u, r, P);
+    r[L - 1] = (uint32_t)acc;
+}
+
 // r -= p if r >= p (r < 2p, limbs normalised)
 template <int B, int L>
 __device__ __forceinline__ void ucond_sub(uint32_t (&r)[L], const UParams<L>& P) {
@@ -331,6 +378,88 @@ struct Chain<N, true> {
     typedef uint32_t Op[L];
     static __device__ __forceinline__ void prep(Op& o, const uint32_t (&w)[N]) { uload_shifted<N>(o, w); }
     __device__ __forceinline__ void mul_op(const Op& o) { mul_limbs(o); }
+};
+
+// ---- PowLadder<N>: square-and-multiply state for k_pow ------------------------------------
+// The unsaturated ladder works in the Montgomery domain of R' = 2^(29 L) = R 2^SH, where nothing
+// needs a pre-shift: squarings are symmetric (umont_sqr: L (L + 1) / 2 products) and, because
+// R' >= 4p for every modulus of the container, values stay in [0, 2p) for the whole ladder, tight
+// moduli included.  Entry: x~ = x 2^SH = umul(x, K) with K = R 2^SH mod p (SH modular doublings of
+// R mod p, once per lane); exit: umont(acc, R mod p) = acc R / R' brings the result back to the
+// reference's radix, then one conditional subtraction.
+template <int N, bool UNSAT = (N >= kUnsatMinN)>
+struct PowLadder;
+
+template <int N>
+struct PowLadder<N, false> {
+    uint32_t acc[N], x[N];
+    const FpParams<N>& P;
+    __device__ __forceinline__ explicit PowLadder(const FpParams<N>& P_) : P(P_) {}
+    __device__ __forceinline__ void start(const uint32_t (&w)[N]) {
+#pragma unroll
+        for (int l = 0; l < N; l++) acc[l] = x[l] = w[l];
+    }
+    __device__ __forceinline__ void square() {
+        uint32_t t[N];
+        mont_mul<N>(t, acc, acc, P);
+#pragma unroll
+        for (int l = 0; l < N; l++) acc[l] = t[l];
+    }
+    __device__ __forceinline__ void mul_base() {
+        uint32_t t[N];
+        mont_mul<N>(t, acc, x, P);
+#pragma unroll
+        for (int l = 0; l < N; l++) acc[l] = t[l];
+    }
+    __device__ __forceinline__ void finish(uint32_t (&w)[N]) const {
+#pragma unroll
+        for (int l = 0; l < N; l++) w[l] = acc[l];
+    }
+};
+
+template <int N>
+struct PowLadder<N, true> {
+    static constexpr int L = UF<N>::L;
+    uint32_t acc[L], x[L], kin[L], kout[L];
+    UParams<L> U;
+    __device__ __forceinline__ explicit PowLadder(const FpParams<N>& P) {
+        uparams_from<N>(U, P);
+        uint32_t k[N], t[N];
+        set_limbs<N>(k, P.one);
+        for (int i = 0; i < UF<N>::SH; i++) {   // K = R 2^SH mod p
+            mod_add<N>(t, k, k, P);
+#pragma unroll
+            for (int l = 0; l < N; l++) k[l] = t[l];
+        }
+        uload_shifted<N>(kin, k);
+        set_limbs<N>(k, P.one);
+        uload<N>(kout, k);
+    }
+    __device__ __forceinline__ void start(const uint32_t (&w)[N]) {
+        uint32_t a[L];
+        uload<N>(a, w);
+        umul<N>(x, a, kin, U);   // x 2^SH, below 2p
+#pragma unroll
+        for (int l = 0; l < L; l++) acc[l] = x[l];
+    }
+    __device__ __forceinline__ void square() {
+        uint32_t t[L];
+        umont_sqr<kUB, L>(t, acc, U);
+#pragma unroll
+        for (int l = 0; l < L; l++) acc[l] = t[l];
+    }
+    __device__ __forceinline__ void mul_base() {
+        uint32_t t[L];
+        umont_mul<kUB, L>(t, acc, x, U);
+#pragma unroll
+        for (int l = 0; l < L; l++) acc[l] = t[l];
+    }
+    __device__ __forceinline__ void finish(uint32_t (&w)[N]) const {
+        uint32_t t[L];
+        umont_mul<kUB, L>(t, acc, kout, U);
+        ucanon<N>(t, U);
+        ustore<N>(w, t);
+    }
 };
 
 }  // namespace fpgpu
