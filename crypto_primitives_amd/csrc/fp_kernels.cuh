@@ -24,7 +24,22 @@ __global__ __launch_bounds__(kBlock) void k_elementwise(const uint32_t* __restri
         uint32_t x[N], y[N], r[N];
         load_elem<N>(x, a, i);
         if constexpr (OP == OP_MUL || OP == OP_ADD || OP == OP_SUB) load_elem<N>(y, b, i);
-        if constexpr (OP == OP_MUL) mont_mul<N>(r, x, y, P);
+        if constexpr ((OP == OP_MUL || OP == OP_SQR) && N >= kUnsatElementwiseMinN) {
+            // wide fields: unsaturated multiplier (fp_unsat.cuh) when the multiplier operand is
+            // canonical; an operand >= p (outside the field, still defined for monty_mul) takes the
+            // saturated path, which forms the reference's integer T for every input
+            UParams<UF<N>::L> U;
+            uparams_from<N>(U, P);
+            uint32_t d[N];
+            const bool canonical = sub_limbs_s<N>(d, OP == OP_MUL ? y : x, P.m) != 0;
+            if (canonical) {
+                if constexpr (OP == OP_MUL) umul_words<N>(r, x, y, U);
+                else usqr_words<N>(r, x, U);
+            } else {
+                if constexpr (OP == OP_MUL) mont_mul<N>(r, x, y, P);
+                else mont_mul<N>(r, x, x, P);
+            }
+        } else if constexpr (OP == OP_MUL) mont_mul<N>(r, x, y, P);
         else if constexpr (OP == OP_SQR) mont_mul<N>(r, x, x, P);
         else if constexpr (OP == OP_ADD) mod_add<N>(r, x, y, P);
         else if constexpr (OP == OP_SUB) mod_sub<N>(r, x, y, P);
