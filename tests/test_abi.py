@@ -95,3 +95,30 @@ def test_rust_sys_crate_binds_every_declared_symbol():
         return 0 if a in ("", "void") else a.count(",") + 1
     for name in c_decl:
         assert nargs(c_decl[name]) == nargs(r_decl[name]), name
+
+
+def test_batch_inv_workspace_plan_is_sane(monkeypatch):
+    """Host arithmetic of the inversion plan: the workspace grows with n, stays a small fraction of
+    the batch for the default chain lengths, and follows the FPGPU_INV_C tuning hook."""
+    lib = cpa.load()
+    f = cpa.MontyField(cpa.BLS12_381_FQ, 6)
+    sizes = [lib.fpgpu_batch_inv_workspace_bytes(f._h, n) for n in (1, 2, 255, 256, 257, 70001, 1 << 20, 1 << 24)]
+    assert all(a <= b for a, b in zip(sizes, sizes[1:])) and sizes[0] > 0
+    assert sizes[-1] < (1 << 24) * 48 // 8          # chains of 32 at the big level: totals are n/32 elements
+    monkeypatch.setenv("FPGPU_INV_C", "2")
+    assert lib.fpgpu_batch_inv_workspace_bytes(f._h, 1 << 20) > (1 << 20) * 48 // 2
+    assert lib.fpgpu_batch_inv_workspace_bytes(f._h, 0) == 0
+
+
+def test_spmv_argument_checks_need_no_gpu():
+    lib = cpa.load()
+    f = cpa.MontyField(cpa.BN254_FR, 4)
+    vals = np.ones((2, 4), dtype=np.uint64)
+    x = np.ones((3, 4), dtype=np.uint64)
+    y = np.zeros((1, 4), dtype=np.uint64)
+    col = np.array([0, 3], dtype=np.uint32)      # 3 is out of range for 3 columns: the reference would panic
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    assert lib.fpgpu_spmv(f._h, p(vals), p(col), 1, 3, 2, p(x), p(y)) == _lib.ERR_SHAPE
+    assert b"column index" in lib.fpgpu_last_error_string()
+    assert lib.fpgpu_spmv(f._h, None, None, 0, 3, 2, None, None) == _lib.OK          # no rows: nothing to do
+    assert lib.fpgpu_spmv_dev(f._h, None, None, 4, 3, 2, None, None, None) == _lib.ERR_SHAPE
