@@ -11,6 +11,7 @@
 //   BoxedMontyField              src/field/crypto_bigint_boxed_monty.rs (runtime limb count)
 //   ConstMontyField<Mod, LIMBS>  src/field/crypto_bigint_const_monty.rs (element style, operators)
 //   DenseRowMatrix<T>            src/matrix.rs:135-164
+//   SparseMatrix<T>              src/matrix.rs:46-61
 //   FieldError::InvalidModulus   src/field.rs:345-349;  "Division by zero"  src/field.rs:155-157
 //
 // As in the reference, SCALAR methods (add, mul, inv, project, lift, ...) run on the host --
@@ -207,6 +208,14 @@ struct DenseRowMatrix {
     const T* row(size_t i) const { return data.data() + i * num_cols; }
 };
 
+// ---- SparseMatrix<T> (src/matrix.rs:46-61): a fixed number of cells per row ---------------
+template <typename T>
+struct SparseMatrix {
+    size_t num_rows = 0, num_cols = 0, density = 0;
+    std::vector<std::pair<size_t, T>> cells;  // (column, value), rows back to back
+    bool is_empty() const { return num_rows == 0 || num_cols == 0; }
+};
+
 // ---- MontyFieldElement<LIMBS> (repr(transparent) over Uint) ------------------------------
 template <size_t LIMBS>
 struct MontyFieldElement {
@@ -376,6 +385,21 @@ class MontyField {
         if (!C.data.empty())
             fpgpu_check(fpgpu_matmul(ctx_.get(), p(A.data.data()), p(B.data.data()), p(C.data.data()), A.num_rows, A.num_cols, B.num_cols));
         return C;
+    }
+    // y = A x over SparseMatrix: the cells' halves travel as two arrays (a Rust tuple has no defined
+    // layout either); an out-of-range column is the reference's index panic
+    std::vector<Element> spmv(const SparseMatrix<Element>& A, const std::vector<Element>& x) const {
+        if (A.num_cols != x.size() || A.cells.size() != A.num_rows * A.density) throw std::invalid_argument("shape mismatch");
+        std::vector<Element> vals(A.cells.size()), y(A.num_rows);
+        std::vector<uint32_t> cols(A.cells.size());
+        for (size_t i = 0; i < A.cells.size(); i++) {
+            if (A.cells[i].first >= A.num_cols) throw std::out_of_range("column index out of range");
+            cols[i] = (uint32_t)A.cells[i].first;
+            vals[i] = A.cells[i].second;
+        }
+        if (A.num_rows)
+            fpgpu_check(fpgpu_spmv(ctx_.get(), p(vals.data()), cols.data(), A.num_rows, A.num_cols, A.density, p(x.data()), p(y.data())));
+        return y;
     }
 
    private:

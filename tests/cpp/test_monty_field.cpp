@@ -221,6 +221,19 @@ static void test_gpu_batches() {
             for (size_t l = 0; l < 300; l++) acc = f.add(acc, f.mul(A.row(i)[l], B.row(l)[j]));
             CHECK(C.row(i)[j] == acc);
         }
+    // sparse: 40 rows, 7 cells per row over 300 columns (repeated columns allowed)
+    SparseMatrix<F::Element> S;
+    S.num_rows = 40; S.num_cols = 300; S.density = 7;
+    {
+        auto sv = random_elems(f, 40 * 7, 6);
+        for (size_t i = 0; i < sv.size(); i++) S.cells.push_back({(i * 37 + i / 7) % 300, sv[i]});
+    }
+    auto ys = f.spmv(S, x);
+    for (size_t i = 0; i < S.num_rows; i++) {
+        auto acc = f.zero();
+        for (size_t j = 0; j < S.density; j++) acc = f.add(acc, f.mul(S.cells[i * 7 + j].second, x[S.cells[i * 7 + j].first]));
+        CHECK(ys[i] == acc);
+    }
     // element style
     using E = ConstMontyField<Bn254, 4>;
     std::vector<E> ea(100), eb(100), eo(100);
