@@ -181,6 +181,12 @@ def main():
             extra[name] = {"Gelem_per_s": n * world * ksteps / wall / 1e9, "kernel_ms": kern * 1e3,
                            "hbm_GBps_per_gpu": bytes_per * n / kern / 1e9,
                            "hbm_frac": bytes_per * n / kern / 1e9 / HBM_PEAK_GBPS}
+        # the remaining elementwise rows of SURVEY.md 8a (A4, A8): one read, one write
+        for name, fn in (("neg", lambda: f.neg_dev(a, out)), ("to_mont", lambda: f.to_mont_dev(a, out)),
+                         ("from_mont", lambda: f.from_mont_dev(a, out))):
+            wall, kern = time_steps(fn, ksteps, 1)
+            extra[name] = {"Gelem_per_s": n * world * ksteps / wall / 1e9, "kernel_ms": kern * 1e3,
+                           "hbm_GBps_per_gpu": 64 * n / kern / 1e9, "hbm_frac": 64 * n / kern / 1e9 / HBM_PEAK_GBPS}
         # register-resident dependent chain: the VALU-bound Gmul/s ("Mul assign" shape)
         nchain, iters = 1 << 22, 256
         wall, kern = time_steps(lambda: f.mul_chain_dev(a[:nchain], b[:nchain], out[:nchain], iters), 5, 1)

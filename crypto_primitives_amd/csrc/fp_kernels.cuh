@@ -9,6 +9,17 @@
 namespace fpgpu {
 
 
+// Which elementwise operations take the unsaturated multiplier (fp_unsat.cuh): the multiplying
+// ones, from 384 bits on, where the saturated multiplier makes them VALU-bound (BLS12-381: sqr
+// 4.26 TB/s and mul 5.13 against 5.4 for add).  Up to 320 bits the saturated multiplier hides
+// behind the memory time; the unsaturated one was tried at 256 bits for the one-read-one-write
+// kernels (sqr 3.35 -> 3.74 ms, to_mont 3.20 -> 3.30 ms over 2^28 elements: the conversions
+// between words and limbs cost more than the carry adds saved) and is not used there.
+template <int N, int OP>
+struct UnsatElementwise {
+    static constexpr bool value = N >= 12 && (OP == OP_MUL || OP == OP_SQR || OP == OP_TO_MONT);
+};
+
 // ---- elementwise: out[i] = op(a[i], b[i]) ------------------------------------------
 // One element per lane per iteration, grid-stride.  Lane i of a wave reads its
 // whole 4N-byte element with 16-byte loads; a wave covers 64 consecutive elements
@@ -24,20 +35,25 @@ __global__ __launch_bounds__(kBlock) void k_elementwise(const uint32_t* __restri
         uint32_t x[N], y[N], r[N];
         load_elem<N>(x, a, i);
         if constexpr (OP == OP_MUL || OP == OP_ADD || OP == OP_SUB) load_elem<N>(y, b, i);
-        if constexpr ((OP == OP_MUL || OP == OP_SQR) && N >= kUnsatElementwiseMinN) {
-            // wide fields: unsaturated multiplier (fp_unsat.cuh) when the multiplier operand is
-            // canonical; an operand >= p (outside the field, still defined for monty_mul) takes the
-            // saturated path, which forms the reference's integer T for every input
+        if constexpr (UnsatElementwise<N, OP>::value) {
+            // unsaturated multiplier (fp_unsat.cuh) when the multiplier operand is canonical; an
+            // operand >= p (outside the field, still defined for monty_mul) takes the saturated path,
+            // which forms the reference's integer T for every input
             UParams<UF<N>::L> U;
             uparams_from<N>(U, P);
-            uint32_t d[N];
-            const bool canonical = sub_limbs_s<N>(d, OP == OP_MUL ? y : x, P.m) != 0;
-            if (canonical) {
-                if constexpr (OP == OP_MUL) umul_words<N>(r, x, y, U);
-                else usqr_words<N>(r, x, U);
+            if constexpr (OP == OP_TO_MONT) {
+                set_limbs<N>(y, P.r2);          // x may be any N-word value; R^2 mod p is canonical
+                umul_words<N>(r, x, y, U);
             } else {
-                if constexpr (OP == OP_MUL) mont_mul<N>(r, x, y, P);
-                else mont_mul<N>(r, x, x, P);
+                uint32_t d[N];
+                const bool canonical = sub_limbs_s<N>(d, OP == OP_MUL ? y : x, P.m) != 0;
+                if (canonical) {
+                    if constexpr (OP == OP_MUL) umul_words<N>(r, x, y, U);
+                    else usqr_words<N>(r, x, U);
+                } else {
+                    if constexpr (OP == OP_MUL) mont_mul<N>(r, x, y, P);
+                    else mont_mul<N>(r, x, x, P);
+                }
             }
         } else if constexpr (OP == OP_MUL) mont_mul<N>(r, x, y, P);
         else if constexpr (OP == OP_SQR) mont_mul<N>(r, x, x, P);

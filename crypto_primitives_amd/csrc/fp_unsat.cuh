@@ -319,10 +319,6 @@ __device__ __forceinline__ void usqr_words(uint32_t (&r)[N], const uint32_t (&a)
     ucanon<N>(t, U);
     ustore<N>(r, t);
 }
-// Wide fields (N >= 12) are VALU-bound in the elementwise mul / sqr with the saturated multiplier
-// (BLS12-381: sqr 4.3 TB/s against 5.4 for add); the unsaturated one brings them back to HBM.
-constexpr int kUnsatElementwiseMinN = 12;
-
 // ---- Chain<N>: the running value of a dependent multiplication chain ----------------------
 // One interface over the two multipliers so that the chain kernels (mul chain, pow, batch
 // inversion, product fold) are written once.  Operands come and go as saturated words, the form
