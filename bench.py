@@ -399,6 +399,13 @@ def cpu_baseline():
     t1 = time.perf_counter()
     o.mul(a[: n // 8], b[: n // 8], threads=1)
     single = (n // 8) / (time.perf_counter() - t1) / 1e9
+    # configs[0] also names add: the same 2^20-element batch through add_mod, ~2 s
+    o.add(a, b, threads=threads)
+    areps, t2 = 0, time.perf_counter()
+    while time.perf_counter() - t2 < 2.0:
+        o.add(a, b, threads=threads)
+        areps += 1
+    add_rate = areps * n / (time.perf_counter() - t2) / 1e9
     # the reference's own bench shape (benches/field_ops_bench_common.rs): 10000 operations on one element,
     # four seeds, eight groups, single core; on its 120-bit bench modulus and on BN254 Fr
     from oracle.fp_oracle import bench_reference_shape
@@ -412,7 +419,7 @@ def cpu_baseline():
             "reference_bench_shape_ns_per_op": ref_shape,
             "sample": "%d passes of a 2^20-element BN254 Fr mul batch (C restatement of monty_mul, "
                       "-O3, OpenMP static chunks); single-thread rate %.4f Gmul/s" % (reps, single),
-            "single_thread_Gmul_per_s": single}
+            "single_thread_Gmul_per_s": single, "add_Gadd_per_s": add_rate}
 
 
 if __name__ == "__main__":
