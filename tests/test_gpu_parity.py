@@ -632,3 +632,23 @@ def test_matmul_multi_limb_every_width(cpa, case):
         A = ints_to_array([rnd.choice((p - 1, p - 2, rnd.randrange(p))) for _ in range(m * k)], n64)
         B = ints_to_array([rnd.choice((p - 1, 1, rnd.randrange(p))) for _ in range(k * n)], n64)
         assert np.array_equal(f.matmul(A, B, m, k, n), o.matmul(A, B, m, k, n, threads=0)), (m, k, n)
+
+
+def test_empty_dimensions(cpa):
+    """Empty folds: a mat-vec over zero columns and a mat-mul over k = 0 are all-zero (sum_refs of
+    nothing, src/semiring.rs:213-226); zero rows write nothing."""
+    import torch
+    for p, n64 in ((cpa.BN254_FR, 4), (cpa.GOLDILOCKS, 1), (cpa.BLS12_381_FQ, 6)):
+        f = cpa.MontyField(p, n64)
+        e = np.zeros((0, n64), dtype=np.uint64)
+        y = f.matvec(e, 5, 0, e)
+        assert y.shape == (5, n64) and not y.any()
+        C = f.matmul(e, e, 3, 0, 4)
+        assert C.shape == (12, n64) and not C.any()
+        assert f.matmul(e, np.ones((28, n64), dtype=np.uint64), 0, 7, 4).shape == (0, n64)
+        assert f.matvec(e, 0, 9, np.ones((9, n64), dtype=np.uint64)).shape == (0, n64)
+        dy = f.alloc(5)
+        dy.fill_(-1)
+        f.matvec_dev(f.alloc(0), 5, 0, f.alloc(0), dy, workspace=torch.empty(256, dtype=torch.uint8, device="cuda"))
+        torch.cuda.synchronize()
+        assert int(dy.count_nonzero()) == 0
