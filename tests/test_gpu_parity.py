@@ -652,3 +652,24 @@ def test_empty_dimensions(cpa):
         f.matvec_dev(f.alloc(0), 5, 0, f.alloc(0), dy, workspace=torch.empty(256, dtype=torch.uint8, device="cuda"))
         torch.cuda.synchronize()
         assert int(dy.count_nonzero()) == 0
+
+
+@pytest.mark.parametrize("hook", ["FPGPU_MATMUL_GENERIC=1", "FPGPU_MATMUL_MFMA=0", "FPGPU_MATVEC_MFMA=0"])
+def test_forced_kernel_paths_agree(cpa, hook, monkeypatch):
+    """The path-forcing hooks of INTEGRATION.md section 4: single-limb mat-mul through the multi-limb
+    kernel and through the VALU kernel, mat-vec through the VALU kernel although a workspace is
+    given - all bit-identical to the oracle."""
+    name, val = hook.split("=")
+    monkeypatch.setenv(name, val)
+    for gname in ("goldilocks", "p64_ref_tests", "bn254_fr"):
+        g = load_golden(gname)
+        p, n64 = h2i(g["modulus"]), g["n64"]
+        f, o = field_of(cpa, g), oracle_of(g)
+        m, k, n = 37, 150, 21
+        A = ints_to_array(synth_elements(p, n64, m * k, 201), n64)
+        B = ints_to_array(synth_elements(p, n64, k * n, 202), n64)
+        want = o.matmul(A, B, m, k, n, threads=0)
+        assert np.array_equal(_dev_matmul(cpa, f, A, B, m, k, n, n64 == 1).reshape(want.shape), want), gname
+        x = ints_to_array(synth_elements(p, n64, k, 203), n64)
+        wy = o.matvec(A, m, k, x, threads=0)
+        assert np.array_equal(_dev_matvec(cpa, f, A, m, k, x, True).reshape(wy.shape), wy), gname
