@@ -370,8 +370,9 @@ struct Chain<N, true> {
     static constexpr int L = UF<N>::L;
     uint32_t v[L];
     UParams<L> U;
+    const uint32_t* pw;   // the modulus as saturated words (kernel argument: stays in SGPRs)
     bool lazy;
-    __device__ __forceinline__ explicit Chain(const FpParams<N>& P) {
+    __device__ __forceinline__ explicit Chain(const FpParams<N>& P) : pw(P.m) {
         uparams_from<N>(U, P);
         lazy = ulazy<N>(P);
     }
@@ -400,8 +401,18 @@ struct Chain<N, true> {
         uint32_t s[L], t[L];
         uload_shifted<N>(s, w);
         umul<N>(t, v, s, U);
-        ucanon<N>(t, U);
-        ustore<N>(out, t);
+        if (lazy) {
+            // 2p < R: the unreduced product fits the words, and the conditional subtraction is
+            // cheaper there (a borrow chain and a select per word instead of five operations per limb)
+            uint32_t x[N], d[N];
+            ustore<N>(x, t);
+            const uint32_t below = sub_limbs_s<N>(d, x, pw);
+#pragma unroll
+            for (int l = 0; l < N; l++) out[l] = below ? x[l] : d[l];
+        } else {
+            ucanon<N>(t, U);
+            ustore<N>(out, t);
+        }
     }
     __device__ __forceinline__ void square() {
         uint32_t s[L];
