@@ -289,6 +289,13 @@ __device__ __forceinline__ bool inv_bingcd(uint32_t (&out)[N], const uint32_t (&
         bingcd_update_uv<N>(nv, u, v, F1, G1, m, P.n0inv);
 #pragma unroll
         for (int i = 0; i < N; i++) { a[i] = na[i]; b[i] = nb[i]; u[i] = nu[i]; v[i] = nv[i]; }
+        // once a == 0, b holds the gcd and further rounds change nothing: leave as soon as that is
+        // true in every lane of the wave (the bound above is the worst case; random inputs need
+        // about two thirds of it)
+        uint32_t anz = 0;
+#pragma unroll
+        for (int i = 0; i < N; i++) anz |= a[i];
+        if (__ballot(anz != 0) == 0) break;
     }
     uint32_t nz = b[0] ^ 1u;
 #pragma unroll
