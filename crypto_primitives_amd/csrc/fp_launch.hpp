@@ -33,8 +33,9 @@ constexpr int kMMTile = 16;   // k_matmul output tile edge
 // chains to fill the chip, where a lane's serial chain is pure latency.
 constexpr int kInvCMin = 8, kInvCMax = 32;
 constexpr size_t kInvLanesWanted = 65536;   // one wave per SIMD
-constexpr size_t kInvTop = 32768; // stop recursing when this few totals remain: one exact inversion per lane
-                                  // costs the same latency for 512 or 32768 lanes, two tree levels do not
+constexpr size_t kInvTop = 65536; // stop recursing when this few totals remain: one exact inversion per lane is
+                                  // pure latency up to one wave per SIMD (2^13 lanes 91 us, 2^16 lanes 103 us on
+                                  // 2^24 BLS12-381 elements), a tree level costs 45 us
 constexpr int kInvMaxLevels = 16;
 struct InvPlan {
     int levels = 0;                         // number of up-sweeps
