@@ -181,6 +181,11 @@ def main():
             wall, kern = time_steps(fn, ksteps, 1)
             extra[name] = {"Gelem_per_s": n * world * ksteps / wall / 1e9, "kernel_ms": kern * 1e3,
                            "hbm_GBps_per_gpu": 64 * n / kern / 1e9, "hbm_frac": 64 * n / kern / 1e9 / HBM_PEAK_GBPS}
+        # in place, a[i] *= b[i] (the reference's MulAssign<&Self>, crypto_bigint_const_monty.rs:337-347): the
+        # same 96 algorithmic bytes per element, written to the lines just read
+        wall, kern = time_steps(lambda: f.mul_dev(out, b, out), ksteps, 1)
+        extra["mul_assign_in_place"] = {"Gelem_per_s": n * world * ksteps / wall / 1e9, "kernel_ms": kern * 1e3,
+                                        "hbm_GBps_per_gpu": 96 * n / kern / 1e9, "hbm_frac": 96 * n / kern / 1e9 / HBM_PEAK_GBPS}
         # register-resident dependent chain: the VALU-bound Gmul/s ("Mul assign" shape)
         nchain, iters = 1 << 22, 256
         wall, kern = time_steps(lambda: f.mul_chain_dev(a[:nchain], b[:nchain], out[:nchain], iters), 5, 1)
