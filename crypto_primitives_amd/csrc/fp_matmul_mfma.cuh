@@ -116,20 +116,24 @@ __global__ __launch_bounds__(256) void k_matmul_mfma_1limb(const uint8_t* __rest
     if (*flag) return;  // some input has no 8-digit form: k_matmul_1limb takes over
     uint32_t rb, cb;
     if (!mf_tile_of(blockIdx.x, rblocks, cblocks, rb, cb)) return;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // the wave index as a scalar: every LDS address and every DMA source below is then a scalar
+    // base plus the lane's 16-byte slot, so a DMA costs two scalar adds, s_mov m0 and the load
+    // itself instead of VALU address arithmetic and a v_readfirstlane per piece
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int wr = wave >> 1, wc = wave & 1;
-    const uint8_t* ga = Aw + (size_t)rb * ksteps * kMF_CHUNK + lane * 16;
-    const uint8_t* gb = Bw + (size_t)cb * ksteps * kMF_CHUNK + lane * 16;
+    const uint32_t lane_off = (uint32_t)lane * 16u;
+    const uint8_t* ga = Aw + (size_t)rb * ksteps * kMF_CHUNK;
+    const uint8_t* gb = Bw + (size_t)cb * ksteps * kMF_CHUNK;
 
     // one eighth of the staging of k-step ks into LDS buffer buf: 32 pieces of 1 KiB per operand,
     // wave w moves pieces w, w+4, ...; part q = 0..7 moves piece 4q + w of A and of B
     auto stage_part = [&](uint32_t ks, int buf, int q) {
         const int piece = q * 4 + wave;
         __builtin_amdgcn_global_load_lds(
-            (const __attribute__((address_space(1))) void*)(ga + (size_t)ks * kMF_CHUNK + piece * 1024),
+            (const __attribute__((address_space(1))) void*)(ga + (size_t)ks * kMF_CHUNK + piece * 1024 + lane_off),
             (__attribute__((address_space(3))) void*)(lds + buf * 2 * kMF_CHUNK + piece * 1024), 16, 0, 0);
         __builtin_amdgcn_global_load_lds(
-            (const __attribute__((address_space(1))) void*)(gb + (size_t)ks * kMF_CHUNK + piece * 1024),
+            (const __attribute__((address_space(1))) void*)(gb + (size_t)ks * kMF_CHUNK + piece * 1024 + lane_off),
             (__attribute__((address_space(3))) void*)(lds + buf * 2 * kMF_CHUNK + kMF_CHUNK + piece * 1024), 16, 0, 0);
     };
 
