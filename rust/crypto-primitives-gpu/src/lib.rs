@@ -351,8 +351,8 @@ mod tests {
     #[test]
     fn batch_equals_scalar() {
         let f = field();
-        let a: Vec<_> = (1u64..200).map(|v| f.project(&(v * 0x9E3779B97F4A7C15))).collect();
-        let b: Vec<_> = (1u64..200).map(|v| f.project(&(v * 0xBF58476D1CE4E5B9))).collect();
+        let a: Vec<_> = (1u64..200).map(|v| f.project(&v.wrapping_mul(0x9E3779B97F4A7C15))).collect();
+        let b: Vec<_> = (1u64..200).map(|v| f.project(&v.wrapping_mul(0xBF58476D1CE4E5B9))).collect();
         let mul = f.mul_batch(&a, &b).unwrap();
         let add = f.add_batch(&a, &b).unwrap();
         let sub = f.sub_batch(&a, &b).unwrap();
