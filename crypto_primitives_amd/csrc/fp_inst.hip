@@ -130,7 +130,8 @@ void Launch<N>::matvec(const fpgpu_ctx* ctx, const void* A, size_t rows, size_t 
             uint8_t* Bw = ws + pl.b_off;
             (void)hipMemsetAsync(ws, 0, pl.b_off, s);
             const size_t ksteps = (size_t)pl.chunks_total * 8;
-            const unsigned eg = (unsigned)(ksteps < 512 ? ksteps : 512);
+            const size_t ebatches = (ksteps + kMV_EXPAND_BATCH - 1) / kMV_EXPAND_BATCH;
+            const unsigned eg = (unsigned)(ebatches < 512 ? ebatches : 512);
             hipLaunchKernelGGL((k_mv_expand<N, NT>), dim3(eg), dim3(NT * 64), 0, s, (const uint32_t*)x, cols, ksteps, Bw,
                                colsum, flag, make_params<N>(ctx));
             hipLaunchKernelGGL((k_matvec_mfma<N, NT>), dim3(pl.rowblocks * pl.ksplit), dim3(kMV_WAVES * 64), 0, s,

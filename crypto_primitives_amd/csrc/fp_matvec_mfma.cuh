@@ -35,27 +35,31 @@
 namespace fpgpu {
 
 constexpr int kMV_CHUNK = 8;       // k-steps (64 bytes of every row) per staged B chunk
+constexpr int kMV_EXPAND_BATCH = 32;  // k-steps a workgroup of k_mv_expand digitises at a time
 typedef int mv_v4i __attribute__((ext_vector_type(4)));
 
 // ---- pre-pass: signed digits of x, their Toeplitz expansion in MFMA fragment order, column sums
 // B chunk layout: k-step ks, column tile nt -> 1 KiB fragment at ((ks * NT) + nt) * 1024, lane
 // l = 16 g + n holds B[64 ks + 16 g + 0..15][16 nt + n].
-// One workgroup of NT waves walks k-steps blockIdx.x, blockIdx.x + gridDim.x, ...
+// One workgroup of NT waves walks batches of kMV_EXPAND_BATCH k-steps: blockIdx.x, blockIdx.x + gridDim.x, ...
 template <int N, int NT>
 __global__ __launch_bounds__(NT * 64) void k_mv_expand(const uint32_t* __restrict__ x, size_t cols, size_t ksteps,
                                                        uint8_t* __restrict__ Bw, unsigned long long* __restrict__ colsum,
                                                        uint32_t* __restrict__ flag, const FpParams<N> P) {
     constexpr int EB = 4 * N;
-    constexpr int MAXEL = 64 / EB + 2;  // elements a 64-byte k-step can touch
+    constexpr int MAXEL = 64 * kMV_EXPAND_BATCH / EB + 2;  // elements a batch of k-steps can touch
     __shared__ int8_t xd[MAXEL][EB];
     const int nt = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15;
     const int d = 16 * nt + n;
     long long csum = 0;
-    for (size_t ks = blockIdx.x; ks < ksteps; ks += gridDim.x) {
-        const size_t c_first = (64 * ks) / EB;
-        __syncthreads();  // previous iteration's readers are done
-        if (threadIdx.x < MAXEL) {
-            const size_t c = c_first + threadIdx.x;
+    // A workgroup takes kMV_EXPAND_BATCH consecutive k-steps at a time: their elements are digitised
+    // into LDS together (two barriers per batch, not per k-step), then every wave writes its column
+    // tile's fragment of each k-step.
+    for (size_t ks0 = (size_t)blockIdx.x * kMV_EXPAND_BATCH; ks0 < ksteps; ks0 += (size_t)gridDim.x * kMV_EXPAND_BATCH) {
+        const size_t c_first = (64 * ks0) / EB;
+        __syncthreads();  // previous batch's readers are done
+        for (int e = threadIdx.x; e < MAXEL; e += NT * 64) {
+            const size_t c = c_first + e;
             uint32_t w[N];
 #pragma unroll
             for (int l = 0; l < N; l++) w[l] = c < cols ? x[c * N + l] : 0u;
@@ -81,30 +85,33 @@ __global__ __launch_bounds__(NT * 64) void k_mv_expand(const uint32_t* __restric
 #pragma unroll
             for (int l = 0; l < N; l++) {
                 const uint32_t u = __builtin_addc(w[l], 0x80808080u, cy, &cy) ^ 0x80808080u;
-                xd[threadIdx.x][4 * l + 0] = (int8_t)(u & 0xff);
-                xd[threadIdx.x][4 * l + 1] = (int8_t)((u >> 8) & 0xff);
-                xd[threadIdx.x][4 * l + 2] = (int8_t)((u >> 16) & 0xff);
-                xd[threadIdx.x][4 * l + 3] = (int8_t)(u >> 24);
+                xd[e][4 * l + 0] = (int8_t)(u & 0xff);
+                xd[e][4 * l + 1] = (int8_t)((u >> 8) & 0xff);
+                xd[e][4 * l + 2] = (int8_t)((u >> 16) & 0xff);
+                xd[e][4 * l + 3] = (int8_t)(u >> 24);
             }
         }
         __syncthreads();
-        uint32_t wds[4];
+        const size_t ks_end = ks0 + kMV_EXPAND_BATCH < ksteps ? ks0 + kMV_EXPAND_BATCH : ksteps;
+        for (size_t ks = ks0; ks < ks_end; ks++) {
+            uint32_t wds[4];
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            uint32_t word = 0;
+            for (int q = 0; q < 4; q++) {
+                uint32_t word = 0;
 #pragma unroll
-            for (int b = 0; b < 4; b++) {
-                const size_t k = 64 * ks + 16 * g + 4 * q + b;
-                const size_t c = k / EB;
-                const int s = (int)(k % EB), t = d - s;
-                int v = 0;
-                if (c < cols && t >= 0 && t < EB) v = xd[c - c_first][t];
-                csum += v;
-                word |= (uint32_t)(v & 0xff) << (8 * b);
+                for (int b = 0; b < 4; b++) {
+                    const size_t k = 64 * ks + 16 * g + 4 * q + b;
+                    const size_t c = k / EB;   // c - c_first <= 64 * kMV_EXPAND_BATCH / EB < MAXEL
+                    const int s = (int)(k % EB), t = d - s;
+                    int v = 0;
+                    if (c < cols && t >= 0 && t < EB) v = xd[c - c_first][t];
+                    csum += v;
+                    word |= (uint32_t)(v & 0xff) << (8 * b);
+                }
+                wds[q] = word;
             }
-            wds[q] = word;
+            *reinterpret_cast<uint4*>(Bw + (ks * NT + nt) * 1024 + lane * 16) = make_uint4(wds[0], wds[1], wds[2], wds[3]);
         }
-        *reinterpret_cast<uint4*>(Bw + (ks * NT + nt) * 1024 + lane * 16) = make_uint4(wds[0], wds[1], wds[2], wds[3]);
     }
     // column sums: lanes n, n+16, n+32, n+48 of a wave share d
     csum += __shfl_xor(csum, 16, 64);
