@@ -155,7 +155,10 @@ void Launch<N>::matvec(const fpgpu_ctx* ctx, const void* A, size_t rows, size_t 
     if (N > 8 && Tmax > 2) Tmax = 2;  // register budget (T = 4 at N = 12 needs 182 VGPRs)
     int T = 1;
     if (t_env > 1) T = t_env < Tmax ? t_env : Tmax;
-    int grid = (int)(rows < 65536 ? rows : 65536);
+    // (as the gated fallback of the matrix-core path the kernel normally exits at once: a small
+    // grid then keeps the empty dispatch at a few microseconds; rows are walked grid-stride)
+    const size_t grid_cap = gate ? 2048 : 65536;
+    int grid = (int)(rows < grid_cap ? rows : grid_cap);
     const uint32_t* Ap = (const uint32_t*)A;
     const uint32_t* xp = (const uint32_t*)x;
     uint32_t* yp = (uint32_t*)y;
