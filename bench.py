@@ -136,7 +136,7 @@ def main():
         # rocprofv3 --pmc on this same command; bench.py cannot run the profiler on itself)
         traffic = None
         try:
-            with open(os.path.join(ROOT, "profiles", "pmc_traffic_%s.json" % args.workload)) as fh:
+            with open(_latest_profile("pmc_traffic_%s.json" % args.workload)) as fh:
                 pmc = json.load(fh)
             if pmc.get("elements") == n:
                 traffic = pmc["traffic_bytes_per_launch"]
@@ -152,7 +152,7 @@ def main():
                        "elements_per_gpu": n, "limbs64": 4, "parallelism": "shard%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "traffic_unit": "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/pmc_traffic_*.json)",
+                         "traffic_unit": "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r*_pmc_traffic_*.json)",
                          "algorithmic_bytes_per_launch": bytes_per * n,
                          "kernel": "k_elementwise<8,%s>" % args.workload, "bytes_per_element": bytes_per,
                          "kernel_ms": kern * 1e3},
@@ -370,10 +370,17 @@ def bench_spmv(f, rank, time_steps):
             "hbm_GBps_per_gpu": bytes_alg / kern / 1e9, "hbm_frac": bytes_alg / kern / 1e9 / HBM_PEAK_GBPS}
 
 
+def _latest_profile(name):
+    """profiles/r<NN>_<name> of the newest round (the summaries are kept per round)."""
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_" + name)))
+    return found[-1] if found else os.path.join(ROOT, "profiles", name)
+
+
 def _pmc_traffic(workload, key, value):
     """HBM bytes per launch from the PMC passes kept under profiles/ (bench.py cannot profile itself)."""
     try:
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic_%s.json" % workload)) as fh:
+        with open(_latest_profile("pmc_traffic_%s.json" % workload)) as fh:
             pmc = json.load(fh)
         return pmc["traffic_bytes_per_launch"] if pmc.get(key) == value else None
     except (OSError, ValueError, KeyError):

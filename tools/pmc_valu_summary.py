@@ -3,6 +3,7 @@ the VALU-bound kernels and the HBM traffic of the add kernel (same corrections a
 import collections, csv, json, sys
 
 src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmcv"
+tag = sys.argv[2] if len(sys.argv) > 2 else "r1"
 
 
 def counters(path):
@@ -41,7 +42,7 @@ for name, disp in valu.items():
         # only meaningful for long kernels: the counter also ticks around a dispatch
         row["shader_clock_GHz"] = avg["GRBM_GUI_ACTIVE"] / 8 / ns if ns > 300e3 else None
     out["kernels"][name.split("(")[0].replace("void fpgpu::", "")] = row
-json.dump(out, open("profiles/pmc_valu_rates.json", "w"), indent=1)
+json.dump(out, open(f"profiles/{tag}_pmc_valu_rates.json", "w"), indent=1)
 print(json.dumps(out, indent=1)[:3000])
 
 # HBM traffic of the add kernel
@@ -60,5 +61,5 @@ t = {"kernel": "k_elementwise<8,add>", "elements": n, "dispatches_averaged": [nf
      "traffic_over_algorithmic": (rd + wr) / (96 * n),
      "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --workload add --steps 3 "
                "--warmup 1 --no-extra --no-cpu (tools/collect_pmc_valu.sh, tools/pmc_valu_summary.py)"}
-json.dump(t, open("profiles/pmc_traffic_add.json", "w"), indent=1)
+json.dump(t, open(f"profiles/{tag}_pmc_traffic_add.json", "w"), indent=1)
 print(json.dumps(t, indent=1))

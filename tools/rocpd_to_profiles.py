@@ -53,7 +53,7 @@ out = {
     "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 3 "
               "--warmup 1 --no-extra --no-cpu (tools/collect_profiles.sh, tools/rocpd_to_profiles.py)",
 }
-json.dump(out, open("profiles/pmc_traffic_mul.json", "w"), indent=1)
+json.dump(out, open(f"profiles/{tag}_pmc_traffic_mul.json", "w"), indent=1)
 print(json.dumps(out, indent=1))
 
 # mat-vec (BASELINE.json configs[3]): traffic of the main kernel
@@ -75,5 +75,5 @@ if os.path.exists(f"{src}/pmc_fetch_mv/f_results.db"):
         "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --workload matvec "
                   "--steps 3 --warmup 1 --no-extra --no-cpu",
     }
-    json.dump(out, open("profiles/pmc_traffic_matvec.json", "w"), indent=1)
+    json.dump(out, open(f"profiles/{tag}_pmc_traffic_matvec.json", "w"), indent=1)
     print(json.dumps(out, indent=1))
