@@ -106,6 +106,16 @@ __device__ __forceinline__ bool mf_tile_of(uint32_t b, uint32_t rblocks, uint32_
     return true;
 }
 
+// The main loop is a fixed instruction order (fp_matmul_kstep.inc, tools/gen_matmul_kstep.py): MFMAs,
+// LDS reads and their waits are asm statements.  Accumulators are pinned to AGPRs by the "+a"
+// constraint -- with the builtin, hipcc moves them between the two register files around every MFMA
+// as soon as a DMA shares the basic block -- so the next k-step's DMAs can be issued from inside the
+// MFMA stream instead of ahead of it (16 DMAs x ~60 cycles of issue per k-step were not hidden at
+// one wave per SIMD).
+#define MF_MFMA(ACC, A, B) asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0" : "+a"(ACC) : "v"(A), "v"(B))
+#define MF_LDS_READ(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:" #OFF : "=v"(DST) : "v"(ADDR) : "memory")
+#define MF_WAIT_LGKM(CNT) asm volatile("s_waitcnt lgkmcnt(" #CNT ")" ::: "memory")
+
 template <int N>  // N == 2 only (see k_matmul_1limb)
 __global__ __launch_bounds__(256) void k_matmul_mfma_1limb(const uint8_t* __restrict__ Aw, const uint8_t* __restrict__ Bw,
                                                            uint2* __restrict__ Cm, size_t m, size_t n, uint32_t rblocks,
@@ -122,6 +132,7 @@ __global__ __launch_bounds__(256) void k_matmul_mfma_1limb(const uint8_t* __rest
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int wr = wave >> 1, wc = wave & 1;
     const uint32_t lane_off = (uint32_t)lane * 16u;
+    const uint32_t lds_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)lds;
     const uint8_t* ga = Aw + (size_t)rb * ksteps * kMF_CHUNK;
     const uint8_t* gb = Bw + (size_t)cb * ksteps * kMF_CHUNK;
 
@@ -149,48 +160,19 @@ __global__ __launch_bounds__(256) void k_matmul_mfma_1limb(const uint8_t* __rest
     for (int q = 0; q < 8; q++) stage_part(0, 0, q);
     __syncthreads();  // (waits for this wave's DMAs, then the barrier)
     for (uint32_t ks = 0; ks < ksteps; ks++) {
-        // The DMA of the next k-step sits in a basic block of its own (in flight while this step
-        // computes).  Folded into the MFMA block, hipcc's register allocation falls apart: it
-        // keeps accumulators in VGPRs and copies them to AGPRs and back around every MFMA.
-#ifndef MF_DBG_NOSTAGE  // (MF_DBG_*: timing experiments only, tools/build_variant.sh)
-        if (ks + 1 < ksteps) {
-#pragma unroll
-            for (int q = 0; q < 8; q++) stage_part(ks + 1, (ks + 1) & 1, q);
-        }
-#endif
-        const uint8_t* base = lds + (ks & 1) * 2 * kMF_CHUNK + lane * 16;
-        mf_v4i a[2][8];
-#pragma unroll
-        for (int i = 0; i < 8; i++)
-#pragma unroll
-            for (int rt = 0; rt < 2; rt++)
-                a[rt][i] = *reinterpret_cast<const mf_v4i*>(base + (i * 4 + 2 * wr + rt) * 1024);
-        auto bfrag = [&](int j, int ct) {
-            return *reinterpret_cast<const mf_v4i*>(base + kMF_CHUNK + (j * 4 + 2 * wc + ct) * 1024);
-        };
-        mf_v4i b[2][2];  // [parity of j][column tile]: digit j+1 is read while digit j's 32 MFMAs run
-        b[0][0] = bfrag(0, 0);
-        b[0][1] = bfrag(0, 1);
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            if (j + 1 < 8) {
-                b[(j + 1) & 1][0] = bfrag(j + 1, 0);
-                b[(j + 1) & 1][1] = bfrag(j + 1, 1);
-            }
-            __builtin_amdgcn_sched_barrier(0);  // or hipcc sinks those reads to just before their use
-            const mf_v4i b0 = b[j & 1][0], b1 = b[j & 1][1];
-#pragma unroll
-            for (int i = 0; i < 8; i++) {
-                acc[i + j][0][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[0][i], b0, acc[i + j][0][0], 0, 0, 0);
-                acc[i + j][0][1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[0][i], b1, acc[i + j][0][1], 0, 0, 0);
-                acc[i + j][1][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[1][i], b0, acc[i + j][1][0], 0, 0, 0);
-                acc[i + j][1][1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[1][i], b1, acc[i + j][1][1], 0, 0, 0);
-            }
-        }
-#ifndef MF_DBG_NOBARRIER
+        // the next k-step's DMAs are issued from inside the MFMA stream, two per digit of B; the
+        // last k-step re-stages itself into the idle buffer so that no branch is needed
+        const uint32_t ks_next = ks + 1 < ksteps ? ks + 1 : ks;
+        mf_v4i a[2][8], b[2][2];  // b: [parity of digit j][column tile], read one digit ahead
+        const uint32_t a_addr = lds_addr + (ks & 1) * 2 * kMF_CHUNK + lane_off + 2 * wr * 1024;
+        const uint32_t b_addr = lds_addr + (ks & 1) * 2 * kMF_CHUNK + kMF_CHUNK + lane_off + 2 * wc * 1024;
+#define MF_STAGE(J) stage_part(ks_next, (ks + 1) & 1, J)
+#include "fp_matmul_kstep.inc"
+#undef MF_STAGE
         __syncthreads();  // next buffer has landed (vmcnt(0) per wave) and this one is free to refill
-#endif
     }
+    // the compiler does not see the asm MFMAs' writes: cover the MFMA-write -> accvgpr-read hazard by hand
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
 
     // ---- recombine the diagonals and reduce: C/D layout col = lane & 15, row = 4 (lane >> 4) + reg
     uint32_t onep[2] = {1u, 0u}, oneR[2], r2[2], zero[2] = {0u, 0u};
