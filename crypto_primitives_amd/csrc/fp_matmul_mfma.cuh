@@ -159,17 +159,31 @@ __global__ __launch_bounds__(256) void k_matmul_mfma_1limb(const uint8_t* __rest
 #pragma unroll
     for (int q = 0; q < 8; q++) stage_part(0, 0, q);
     __syncthreads();  // (waits for this wave's DMAs, then the barrier)
+#ifdef MF_DBG_ONEK  // (timing of the per-tile prologue + epilogue alone)
+    for (uint32_t ks = 0; ks < 1; ks++) {
+#else
     for (uint32_t ks = 0; ks < ksteps; ks++) {
+#endif
         // the next k-step's DMAs are issued from inside the MFMA stream, two per digit of B; the
         // last k-step re-stages itself into the idle buffer so that no branch is needed
         const uint32_t ks_next = ks + 1 < ksteps ? ks + 1 : ks;
         mf_v4i a[2][8], b[2][2];  // b: [parity of digit j][column tile], read one digit ahead
         const uint32_t a_addr = lds_addr + (ks & 1) * 2 * kMF_CHUNK + lane_off + 2 * wr * 1024;
         const uint32_t b_addr = lds_addr + (ks & 1) * 2 * kMF_CHUNK + kMF_CHUNK + lane_off + 2 * wc * 1024;
+#ifdef MF_DBG_NOSTAGE  // (MF_DBG_*: timing experiments only, results are wrong; tools/build_variant.sh)
+#define MF_STAGE(J)
+#elif defined(MF_DBG_SAMEK)
+#define MF_STAGE(J) stage_part(0, (ks + 1) & 1, J)
+#elif defined(MF_DBG_HALFSTAGE)
+#define MF_STAGE(J) if ((J) & 1) stage_part(ks_next, (ks + 1) & 1, J)
+#else
 #define MF_STAGE(J) stage_part(ks_next, (ks + 1) & 1, J)
+#endif
 #include "fp_matmul_kstep.inc"
 #undef MF_STAGE
+#ifndef MF_DBG_NOBARRIER
         __syncthreads();  // next buffer has landed (vmcnt(0) per wave) and this one is free to refill
+#endif
     }
     // the compiler does not see the asm MFMAs' writes: cover the MFMA-write -> accvgpr-read hazard by hand
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
