@@ -397,7 +397,8 @@ def _dev_matmul(cpa, f, A, B, m, k, n, use_ws):
     return dC.cpu().numpy().view(np.uint64)
 
 
-@pytest.mark.parametrize("shape", [(1, 1, 1), (64, 64, 64), (65, 63, 130), (17, 500, 33), (200, 1000, 70), (3, 16320, 5)])
+@pytest.mark.parametrize("shape", [(1, 1, 1), (64, 64, 64), (65, 63, 130), (17, 500, 33), (200, 1000, 70), (3, 16320, 5),
+                                   (70, 130, 66), (130, 192, 70), (128, 2100, 129)])
 def test_matmul_matrix_core_path_vs_oracle(cpa, shape):
     """Single-limb mat-mul through the int8 matrix-core kernel (workspace given) == oracle == VALU kernel,
     on uniform elements and on the values that make the largest signed digits."""
