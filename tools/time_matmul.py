@@ -5,13 +5,15 @@ import numpy as np, torch
 import crypto_primitives_amd as cpa
 dim = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 f = cpa.MontyField(cpa.GOLDILOCKS, 1)
+# BALLAST=<GiB>: memory held (and touched) before the operands are allocated, as in bench.py's extras
+ballast = [torch.zeros(1 << 30, dtype=torch.uint8, device="cuda") for _ in range(int(os.environ.get("BALLAST", "0")))]
 A = f.random_dev(dim * dim, 1); B = f.random_dev(dim * dim, 2); C = f.alloc(dim * dim)
 ws = None
 if os.environ.get("NO_WS") != "1":
     ws = torch.empty(f.matmul_workspace_bytes(dim, dim, dim), dtype=torch.uint8, device="cuda")
 f.matmul_dev(A, B, C, dim, dim, dim, workspace=ws); torch.cuda.synchronize()
 e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-reps = 3
+reps = int(os.environ.get("REPS", "3"))
 e0.record()
 for _ in range(reps): f.matmul_dev(A, B, C, dim, dim, dim, workspace=ws)
 e1.record(); torch.cuda.synchronize()
