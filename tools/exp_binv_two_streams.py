@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import crypto_primitives_amd as cpa
 f = cpa.MontyField(cpa.BLS12_381_FQ, 6)
-n = 1 << 24
+n = 1 << int(os.environ.get("LOG2N", "24"))
 x = f.random_dev(n, 7); out = f.alloc(n)
 flags = torch.empty(n, dtype=torch.uint8, device="cuda")
 def timed(fn, reps=10):
