@@ -310,13 +310,22 @@ def bench_matmul(args, world, rank, distributed, time_steps, primary):
            "valu_kernel_ms_for_comparison": 125.8}
     if primary:
         extra_fields = {"ms_per_step_with_allgather_of_C": gathered_ms}
+        traffic = None   # HBM bytes per launch of the main kernel from the PMC passes under profiles/ (N = 1 shape)
+        try:
+            with open(_latest_profile("pmc_matmul.json")) as fh:
+                pmc = json.load(fh)
+            if pmc.get("dim") == dim and world == 1:
+                traffic = pmc["traffic_bytes_per_launch"]
+        except (OSError, ValueError, KeyError):
+            pass
         res = {"metric": "64-bit Fp mat-mul Gterms/s (Goldilocks, 8192^2)", "value": res["Gterms_per_s"],
                "unit": "Gterms/s", "per_gpu": res["Gterms_per_s"] / world, "ms_per_step": res["ms_per_matmul"],
                "config": {"workload": "Goldilocks 64-bit 8192 x 8192 x 8192 mat-mul (BASELINE.json configs[4])",
                           "parallelism": "rowshard%d (C stays row-sharded)" % world, **extra_fields},
                "roofline": {"bound": "mfma", "achieved": tops, "peak": MFMA_I8_PEAK_TOPS,
                             "unit": "TOP/s (int8 multiply-accumulates x 2; 64 per 64x64-bit term)",
-                            "frac": tops / MFMA_I8_PEAK_TOPS, "traffic": None,
+                            "frac": tops / MFMA_I8_PEAK_TOPS, "traffic": traffic,
+                            "traffic_unit": "HBM bytes per launch of k_matmul_mfma_1limb (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r*_pmc_matmul.json)",
                             "kernel": "k_matmul_mfma_1limb"},
                "verified_vs_oracle": None}
     return res

@@ -6,6 +6,8 @@ OUT=gpurun_out/pmc_mm
 mkdir -p $OUT
 timeout -s KILL 150 rocprofv3 --pmc FETCH_SIZE -d $OUT/fetch -o f -- python3 bench.py --workload matmul --steps 2 --warmup 1 --no-extra --no-cpu > $OUT/fetch.log 2>&1
 echo "fetch done"
+timeout -s KILL 150 rocprofv3 --pmc WRITE_SIZE -d $OUT/write -o w -- python3 bench.py --workload matmul --steps 2 --warmup 1 --no-extra --no-cpu > $OUT/write.log 2>&1
+echo "write done"
 timeout -s KILL 150 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum -d $OUT/hit -o h -- python3 bench.py --workload matmul --steps 2 --warmup 1 --no-extra --no-cpu > $OUT/hit.log 2>&1
 echo "hit/miss done"
 timeout -s KILL 150 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d $OUT/mfma -o m -- python3 bench.py --workload matmul --steps 2 --warmup 1 --no-extra --no-cpu > $OUT/mfma.log 2>&1
