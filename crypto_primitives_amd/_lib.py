@@ -56,6 +56,7 @@ SIGNATURES = {
     "fpgpu_batch_inv": (_int, [_vp, _vp, _vp, _vp, _sz]),
     "fpgpu_matvec": (_int, [_vp, _vp, _sz, _sz, _vp, _vp]),
     "fpgpu_matmul": (_int, [_vp, _vp, _vp, _vp, _sz, _sz, _sz]),
+    "fpgpu_tuning_set": (_int, [_c.c_char_p, _c.c_long]),
     "fpgpu_last_error_string": (_c.c_char_p, []),
     "fpgpu_device_count": (_int, []),
     "fpgpu_version": (_c.c_char_p, []),
@@ -87,6 +88,14 @@ def load():
             fn.argtypes = args
         _lib = lib
     return _lib
+
+
+TUNING_DEFAULT = -0x7fffffff - 1
+
+
+def tuning_set(name, value=TUNING_DEFAULT):
+    """Set one tuning / test hook; TUNING_DEFAULT restores the library's choice."""
+    check(load().fpgpu_tuning_set(name.encode(), value))
 
 
 class FpgpuError(RuntimeError):

@@ -1,6 +1,4 @@
 // fp_inst.hip -- instantiates every kernel launcher for ONE limb count (-DFPGPU_N=N).
-#include <cstdlib>
-
 #include "fp_kernels.cuh"
 #include "fp_launch.hpp"
 #if FPGPU_N == 2
@@ -37,7 +35,7 @@ static void launch_ew(const fpgpu_ctx* ctx, const void* a, const void* b, void* 
 }
 
 template <int N>
-void Launch<N>::elementwise(int op, const fpgpu_ctx* ctx, const void* a, const void* b, void* out, size_t n,
+hipError_t Launch<N>::elementwise(int op, const fpgpu_ctx* ctx, const void* a, const void* b, void* out, size_t n,
                             hipStream_t s) {
     switch (op) {
         case OP_MUL: launch_ew<N, OP_MUL>(ctx, a, b, out, n, s); break;
@@ -47,19 +45,21 @@ void Launch<N>::elementwise(int op, const fpgpu_ctx* ctx, const void* a, const v
         case OP_NEG: launch_ew<N, OP_NEG>(ctx, a, b, out, n, s); break;
         case OP_TO_MONT: launch_ew<N, OP_TO_MONT>(ctx, a, b, out, n, s); break;
         case OP_FROM_MONT: launch_ew<N, OP_FROM_MONT>(ctx, a, b, out, n, s); break;
-        default: break;
+        default: return hipErrorInvalidValue;
     }
+    return hipSuccess;
 }
 
 template <int N>
-void Launch<N>::mul_chain(const fpgpu_ctx* ctx, const void* a, const void* b, void* out, size_t n, uint32_t iters,
+hipError_t Launch<N>::mul_chain(const fpgpu_ctx* ctx, const void* a, const void* b, void* out, size_t n, uint32_t iters,
                           hipStream_t s) {
     hipLaunchKernelGGL((k_mul_chain<N>), dim3(grid_for(n)), dim3(kBlock), 0, s, (const uint32_t*)a,
                        (const uint32_t*)b, (uint32_t*)out, n, iters, make_params<N>(ctx));
+    return hipSuccess;
 }
 
 template <int N>
-void Launch<N>::batch_inv(const fpgpu_ctx* ctx, const void* x, void* out, uint8_t* flags, size_t n, char* ws,
+hipError_t Launch<N>::batch_inv(const fpgpu_ctx* ctx, const void* x, void* out, uint8_t* flags, size_t n, char* ws,
                           hipStream_t s) {
     const InvPlan p = make_inv_plan(ctx->n64, n);
     const FpParams<N> P = make_params<N>(ctx);
@@ -68,7 +68,7 @@ void Launch<N>::batch_inv(const fpgpu_ctx* ctx, const void* x, void* out, uint8_
     auto O = [&](int l) -> uint32_t* { return l == 0 ? (uint32_t*)out : (uint32_t*)(ws + p.o_off[l]); };
     uint8_t* poisoned = (uint8_t*)(ws + p.poison_off);
     uint32_t* any_poisoned = (uint32_t*)(ws + p.any_off);
-    (void)hipMemsetAsync(any_poisoned, 0, sizeof(uint32_t), s);
+    if (hipError_t e = hipMemsetAsync(any_poisoned, 0, sizeof(uint32_t), s); e != hipSuccess) return e;
     // up-sweeps
     for (int l = 0; l < p.levels; l++) {
         int blocks = blocks_for(l);
@@ -107,28 +107,29 @@ void Launch<N>::batch_inv(const fpgpu_ctx* ctx, const void* x, void* out, uint8_
     const int fb_blocks = grid_for(n) < 2048 ? grid_for(n) : 2048;
     hipLaunchKernelGGL((k_binv_fallback<N>), dim3(fb_blocks), dim3(kBlock), 0, s, (const uint32_t*)x,
                        (uint32_t*)out, flags, poisoned, any_poisoned, n, p.levels, chains, P);
+    return hipSuccess;
 }
 
 template <int N>
-void Launch<N>::matvec(const fpgpu_ctx* ctx, const void* A, size_t rows, size_t cols, const void* x, void* y,
+hipError_t Launch<N>::matvec(const fpgpu_ctx* ctx, const void* A, size_t rows, size_t cols, const void* x, void* y,
                        void* workspace, size_t workspace_bytes, hipStream_t s) {
-    // Matrix-core path (fp_matvec_mfma.cuh) when the caller brings the workspace; FPGPU_MATVEC_MFMA=0
-    // forces the VALU kernel (A/B checks and timing).  The VALU kernel still runs after it, gated by
-    // the digitiser's flag (x not representable in signed digits).
+    // Matrix-core path (fp_matvec_mfma.cuh) when the caller brings the workspace; the tuning hook
+    // matvec_mfma = 0 forces the VALU kernel (A/B checks and timing).  The VALU kernel still runs
+    // after it, gated by the digitiser's flag (x not representable in signed digits).
+    const Tuning& tune = tuning();
     const uint32_t* gate = nullptr;
     {
         MvPlan pl = make_mv_plan(ctx->n64, rows, cols);
-        const char* e = getenv("FPGPU_MATVEC_MFMA");
-        const char* ksp = getenv("FPGPU_MATVEC_KSPLIT");  // tuning / test hook: column parts per row block
-        if (ksp && atoi(ksp) > 0 && pl.usable) pl.ksplit = (uint32_t)atoi(ksp) < pl.chunks_total ? (uint32_t)atoi(ksp) : pl.chunks_total;
-        if (pl.usable && workspace && workspace_bytes >= pl.bytes && !(e && !atoi(e)) && (uintptr_t)A % 16 == 0) {
+        const long ksp = tune.matvec_ksplit;  // tuning / test hook: column parts per row block
+        if (ksp > 0 && pl.usable) pl.ksplit = (uint32_t)ksp < pl.chunks_total ? (uint32_t)ksp : pl.chunks_total;
+        if (pl.usable && workspace && workspace_bytes >= pl.bytes && tune.matvec_mfma != 0 && (uintptr_t)A % 16 == 0) {
             constexpr int NT = N / 2;
             uint8_t* ws = (uint8_t*)workspace;
             uint32_t* flag = (uint32_t*)ws;
             unsigned long long* colsum = (unsigned long long*)(ws + pl.colsum_off);
             unsigned long long* Dbuf = (unsigned long long*)(ws + pl.d_off);
             uint8_t* Bw = ws + pl.b_off;
-            (void)hipMemsetAsync(ws, 0, pl.b_off, s);
+            if (hipError_t e = hipMemsetAsync(ws, 0, pl.b_off, s); e != hipSuccess) return e;
             const size_t ksteps = (size_t)pl.chunks_total * 8;
             const size_t ebatches = (ksteps + kMV_EXPAND_BATCH - 1) / kMV_EXPAND_BATCH;
             const unsigned eg = (unsigned)(ebatches < 512 ? ebatches : 512);
@@ -146,9 +147,8 @@ void Launch<N>::matvec(const fpgpu_ctx* ctx, const void* A, size_t rows, size_t 
     // if T*p <= R, i.e. the modulus leaves log2(T) zero bits at the top of its container.
     // Measured on MI355X (2^15 x 2^15, BN254): T = 1 (66 VGPRs, 7 waves/SIMD) 6.96 ms,
     // T = 2 7.3 ms, T = 4 (125 VGPRs, 4 waves) 7.9 ms -- occupancy beats the saved column
-    // shifts, so T = 1 is the default; FPGPU_MATVEC_T selects 2 or 4 for experiments.
-    const char* t_str = getenv("FPGPU_MATVEC_T");  // read per call so tests can cover every T
-    const int t_env = t_str ? atoi(t_str) : 0;
+    // shifts, so T = 1 is the default; the tuning hook matvec_t selects 2 or 4 for experiments.
+    const int t_env = (int)tune.matvec_t;
     int lz = __builtin_clzll(ctx->modulus[ctx->n64 - 1] | 1);
     if (ctx->modulus[ctx->n64 - 1] == 0) lz = 64;
     int Tmax = lz >= 2 ? 4 : (lz >= 1 ? 2 : 1);
@@ -168,30 +168,30 @@ void Launch<N>::matvec(const fpgpu_ctx* ctx, const void* A, size_t rows, size_t 
         hipLaunchKernelGGL((k_matvec<N, 2>), dim3(grid), dim3(kBlock), 0, s, Ap, xp, yp, rows, cols, gate, make_params<N>(ctx));
     else
         hipLaunchKernelGGL((k_matvec<N, 1>), dim3(grid), dim3(kBlock), 0, s, Ap, xp, yp, rows, cols, gate, make_params<N>(ctx));
+    return hipSuccess;
 }
 
 template <int N>
-void Launch<N>::matmul(const fpgpu_ctx* ctx, const void* A, const void* B, void* C, size_t m, size_t k, size_t n,
+hipError_t Launch<N>::matmul(const fpgpu_ctx* ctx, const void* A, const void* B, void* C, size_t m, size_t k, size_t n,
                        void* workspace, size_t workspace_bytes, hipStream_t s) {
 #if FPGPU_N == 2
     {
-        // single-limb paths; FPGPU_MATMUL_GENERIC=1 forces the generic kernel, FPGPU_MATMUL_MFMA=0
-        // the VALU kernel (A/B checks and timing)
-        const char* g = getenv("FPGPU_MATMUL_GENERIC");
-        if (!(g && atoi(g))) {
+        // single-limb paths; the tuning hooks matmul_generic = 1 force the generic kernel,
+        // matmul_mfma = 0 the VALU kernel (A/B checks and timing)
+        const Tuning& tune = tuning();
+        if (tune.matmul_generic <= 0) {
             const size_t gx = (n + kMM1_BN - 1) / kMM1_BN, gy = (m + kMM1_BM - 1) / kMM1_BM;
             const MfmaPlan pl = make_mfma_plan(ctx->n64, m, k, n);
-            const char* e = getenv("FPGPU_MATMUL_MFMA");
-            const bool mfma = pl.usable && workspace && workspace_bytes >= pl.bytes && !(e && !atoi(e));
+            const bool mfma = pl.usable && workspace && workspace_bytes >= pl.bytes && tune.matmul_mfma != 0;
             if (!mfma) {
                 hipLaunchKernelGGL((k_matmul_1limb<N>), dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, s,
                                    (const uint2*)A, (const uint2*)B, (uint2*)C, m, k, n, (const uint32_t*)nullptr,
                                    make_params<N>(ctx));
-                return;
+                return hipSuccess;
             }
             uint8_t* ws = (uint8_t*)workspace;
             uint32_t* flag = (uint32_t*)ws;
-            (void)hipMemsetAsync(flag, 0, 4, s);
+            if (hipError_t e = hipMemsetAsync(flag, 0, 4, s); e != hipSuccess) return e;
             const unsigned wa = pl.rblocks * pl.ksteps, wb = pl.cblocks * pl.ksteps;  // x4 waves = one workgroup each
             hipLaunchKernelGGL((k_mf_digitize<false>), dim3(wa), dim3(256), 0, s, (const uint64_t*)A, m, k, k,
                                ws + pl.a_off, pl.rblocks, pl.ksteps, ctx->modulus[0], flag);
@@ -203,7 +203,7 @@ void Launch<N>::matmul(const fpgpu_ctx* ctx, const void* A, const void* B, void*
                                make_params<N>(ctx));
             hipLaunchKernelGGL((k_matmul_1limb<N>), dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, s, (const uint2*)A,
                                (const uint2*)B, (uint2*)C, m, k, n, (const uint32_t*)flag, make_params<N>(ctx));
-            return;
+            return hipSuccess;
         }
     }
 #endif
@@ -212,16 +212,18 @@ void Launch<N>::matmul(const fpgpu_ctx* ctx, const void* A, const void* B, void*
     size_t gx = (n + kMMTile - 1) / kMMTile, gy = (m + kMMTile - 1) / kMMTile;
     hipLaunchKernelGGL((k_matmul<N>), dim3((unsigned)gx, (unsigned)gy), dim3(kMMTile * kMMTile), 0, s,
                        (const uint32_t*)A, (const uint32_t*)B, (uint32_t*)C, m, k, n, make_params<N>(ctx));
+    return hipSuccess;
 }
 
 template <int N>
-void Launch<N>::fill_random(const fpgpu_ctx* ctx, void* out, size_t n, uint64_t seed, hipStream_t s) {
+hipError_t Launch<N>::fill_random(const fpgpu_ctx* ctx, void* out, size_t n, uint64_t seed, hipStream_t s) {
     hipLaunchKernelGGL((k_fill_random<N>), dim3(grid_for(n)), dim3(kBlock), 0, s, (uint32_t*)out, n, seed,
                        make_params<N>(ctx));
+    return hipSuccess;
 }
 
 template <int N>
-void Launch<N>::spmv(const fpgpu_ctx* ctx, const void* vals, const uint32_t* colidx, size_t rows, size_t cols,
+hipError_t Launch<N>::spmv(const fpgpu_ctx* ctx, const void* vals, const uint32_t* colidx, size_t rows, size_t cols,
                      uint32_t density, const void* x, void* y, hipStream_t s) {
     // G = 2^log2g lanes share a row, about two cells each.  The kernel is bound by the latency and
     // the line granularity of the gather of x (each 32-byte element drags a 128-byte line through
@@ -230,27 +232,29 @@ void Launch<N>::spmv(const fpgpu_ctx* ctx, const void* vals, const uint32_t* col
     // 8: 45.7, 16: 48.2, 32: 47.6.
     uint32_t log2g = 0;
     while ((2u << log2g) < density && log2g < 6) log2g++;
-    if (const char* e = getenv("FPGPU_SPMV_LOG2G")) { int v = atoi(e); if (v >= 0 && v <= 6) log2g = (uint32_t)v; }  // tuning / tests
+    if (const long v = tuning().spmv_log2g; v >= 0 && v <= 6) log2g = (uint32_t)v;  // tuning / tests
     const size_t lanes = rows << log2g;
     size_t blocks = (lanes + kBlock - 1) / kBlock;
     if (blocks > (1u << 20)) blocks = 1u << 20;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL((k_spmv<N>), dim3((unsigned)blocks), dim3(kBlock), 0, s, (const uint32_t*)vals, colidx,
                        (const uint32_t*)x, (uint32_t*)y, rows, cols, density, log2g, make_params<N>(ctx));
+    return hipSuccess;
 }
 
 template <int N>
-void Launch<N>::pow(const fpgpu_ctx* ctx, const void* a, const uint32_t* exp32, int top_bit, void* out, size_t n,
+hipError_t Launch<N>::pow(const fpgpu_ctx* ctx, const void* a, const uint32_t* exp32, int top_bit, void* out, size_t n,
                     hipStream_t s) {
     PowExp e;
     for (int i = 0; i < 16; i++) e.w[i] = exp32[i];
     e.top = top_bit;
     hipLaunchKernelGGL((k_pow<N>), dim3(grid_for(n)), dim3(kBlock), 0, s, (const uint32_t*)a, (uint32_t*)out, n, e,
                        make_params<N>(ctx));
+    return hipSuccess;
 }
 
 template <int N>
-void Launch<N>::fold(bool product, const fpgpu_ctx* ctx, const void* v, size_t n, void* out, void* ws,
+hipError_t Launch<N>::fold(bool product, const fpgpu_ctx* ctx, const void* v, size_t n, void* out, void* ws,
                      hipStream_t s) {
     size_t blocks = (n + kBlock - 1) / kBlock;
     if (blocks > (size_t)kFoldBlocks) blocks = kFoldBlocks;
@@ -264,6 +268,7 @@ void Launch<N>::fold(bool product, const fpgpu_ctx* ctx, const void* v, size_t n
         if (product) hipLaunchKernelGGL((k_fold<N, true>), dim3(1), dim3(kBlock), 0, s, (const uint32_t*)ws, blocks, (uint32_t*)out, P);
         else hipLaunchKernelGGL((k_fold<N, false>), dim3(1), dim3(kBlock), 0, s, (const uint32_t*)ws, blocks, (uint32_t*)out, P);
     }
+    return hipSuccess;
 }
 
 template struct Launch<FPGPU_N>;

@@ -102,26 +102,44 @@ inline MfmaPlan make_mfma_plan(uint32_t n64, size_t m, size_t k, size_t n) {
 constexpr int kFoldBlocks = 2048;  // partials of the first fold pass (workspace = kFoldBlocks elements)
 int grid_for(size_t n);
 
+// Tuning / test hooks.  None changes a result.  They are read from the
+// environment ONCE, when the library is first used, and can be set afterwards with
+// fpgpu_tuning_set(); the launchers only read these words (no getenv on any call path).
+// 0 (or -1 where 0 is a legal value) = the library's default.
+struct Tuning {
+    long grid_cap = 0;        // FPGPU_GRID_CAP: workgroup cap of the streaming kernels
+    long inv_c = 0;           // FPGPU_INV_C: chain length of every batch-inversion level
+    long matvec_mfma = -1;    // FPGPU_MATVEC_MFMA: 0 forces the VALU mat-vec
+    long matvec_ksplit = 0;   // FPGPU_MATVEC_KSPLIT: column parts per row block (matrix-core mat-vec)
+    long matvec_t = 0;        // FPGPU_MATVEC_T: products per pass of the VALU mat-vec
+    long matmul_mfma = -1;    // FPGPU_MATMUL_MFMA: 0 forces the VALU single-limb mat-mul
+    long matmul_generic = 0;  // FPGPU_MATMUL_GENERIC: 1 forces the multi-limb mat-mul kernel
+    long spmv_log2g = -1;     // FPGPU_SPMV_LOG2G: log2 of the lanes sharing a sparse row
+};
+const Tuning& tuning();
+
+// Every launcher returns the first HIP error of the calls it makes (memsets included); the kernel
+// launches themselves are checked by the caller with hipGetLastError().
 template <int N>
 struct Launch {
-    static void elementwise(int op, const fpgpu_ctx* ctx, const void* a, const void* b, void* out, size_t n,
+    static hipError_t elementwise(int op, const fpgpu_ctx* ctx, const void* a, const void* b, void* out, size_t n,
                             hipStream_t s);
-    static void mul_chain(const fpgpu_ctx* ctx, const void* a, const void* b, void* out, size_t n, uint32_t iters,
+    static hipError_t mul_chain(const fpgpu_ctx* ctx, const void* a, const void* b, void* out, size_t n, uint32_t iters,
                           hipStream_t s);
-    static void batch_inv(const fpgpu_ctx* ctx, const void* x, void* out, uint8_t* flags, size_t n, char* ws,
+    static hipError_t batch_inv(const fpgpu_ctx* ctx, const void* x, void* out, uint8_t* flags, size_t n, char* ws,
                           hipStream_t s);
-    static void matvec(const fpgpu_ctx* ctx, const void* A, size_t rows, size_t cols, const void* x, void* y,
+    static hipError_t matvec(const fpgpu_ctx* ctx, const void* A, size_t rows, size_t cols, const void* x, void* y,
                        void* workspace, size_t workspace_bytes,
                        hipStream_t s);
-    static void matmul(const fpgpu_ctx* ctx, const void* A, const void* B, void* C, size_t m, size_t k, size_t n,
+    static hipError_t matmul(const fpgpu_ctx* ctx, const void* A, const void* B, void* C, size_t m, size_t k, size_t n,
                        void* workspace, size_t workspace_bytes,
                        hipStream_t s);
-    static void fill_random(const fpgpu_ctx* ctx, void* out, size_t n, uint64_t seed, hipStream_t s);
-    static void spmv(const fpgpu_ctx* ctx, const void* vals, const uint32_t* colidx, size_t rows, size_t cols,
+    static hipError_t fill_random(const fpgpu_ctx* ctx, void* out, size_t n, uint64_t seed, hipStream_t s);
+    static hipError_t spmv(const fpgpu_ctx* ctx, const void* vals, const uint32_t* colidx, size_t rows, size_t cols,
                      uint32_t density, const void* x, void* y, hipStream_t s);
-    static void pow(const fpgpu_ctx* ctx, const void* a, const uint32_t* exp32, int top_bit, void* out, size_t n,
+    static hipError_t pow(const fpgpu_ctx* ctx, const void* a, const uint32_t* exp32, int top_bit, void* out, size_t n,
                     hipStream_t s);
-    static void fold(bool product, const fpgpu_ctx* ctx, const void* v, size_t n, void* out, void* ws,
+    static hipError_t fold(bool product, const fpgpu_ctx* ctx, const void* v, size_t n, void* out, void* ws,
                      hipStream_t s);
 };
 

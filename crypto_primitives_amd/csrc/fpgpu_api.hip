@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -69,6 +70,29 @@ uint64_t neg_inv64(uint64_t m0) {
 
 namespace fpgpu {
 
+// The tuning words: environment once (first use), fpgpu_tuning_set afterwards.
+struct TuningEntry {
+    const char* name;
+    long Tuning::*field;
+};
+static const TuningEntry kTuningEntries[] = {
+    {"FPGPU_GRID_CAP", &Tuning::grid_cap},         {"FPGPU_INV_C", &Tuning::inv_c},
+    {"FPGPU_MATVEC_MFMA", &Tuning::matvec_mfma},   {"FPGPU_MATVEC_KSPLIT", &Tuning::matvec_ksplit},
+    {"FPGPU_MATVEC_T", &Tuning::matvec_t},         {"FPGPU_MATMUL_MFMA", &Tuning::matmul_mfma},
+    {"FPGPU_MATMUL_GENERIC", &Tuning::matmul_generic}, {"FPGPU_SPMV_LOG2G", &Tuning::spmv_log2g},
+};
+static Tuning g_tuning_defaults;
+static Tuning g_tuning;
+static std::once_flag g_tuning_once;
+static Tuning& tuning_mutable() {
+    std::call_once(g_tuning_once, [] {
+        for (const TuningEntry& t : kTuningEntries)
+            if (const char* e = getenv(t.name); e && *e) g_tuning.*(t.field) = atol(e);
+    });
+    return g_tuning;
+}
+const Tuning& tuning() { return tuning_mutable(); }
+
 int grid_for(size_t n) {
     // One element per lane up to 2^20 workgroups, grid-stride beyond.  Measured on the
     // 2^28-element BN254 mul (MI355X): cap 2048 4.99 TB/s, 16384 5.22, 65536 5.38,
@@ -76,7 +100,7 @@ int grid_for(size_t n) {
     // pipeline fuller than long grid-stride loops for these VALU-heavy streams.
     size_t blocks = (n + kBlock - 1) / kBlock;
     size_t cap = (size_t)1 << 20;
-    if (const char* e = getenv("FPGPU_GRID_CAP")) { long v = atol(e); if (v > 0) cap = (size_t)v; }  // tuning only
+    if (const long v = tuning().grid_cap; v > 0) cap = (size_t)v;  // tuning only
     return (int)std::min<size_t>(std::max<size_t>(blocks, 1), cap);
 }
 
@@ -90,7 +114,7 @@ InvPlan make_inv_plan(uint32_t n64, size_t n) {
         size_t c = p.count[p.levels];
         int len = kInvCMin;
         while (len < kInvCMax && c / (2 * (size_t)len) >= kInvLanesWanted) len *= 2;
-        if (const char* e = getenv("FPGPU_INV_C")) { int v = atoi(e); if (v >= 2 && v <= 1024) len = v; }  // tuning / tests
+        if (const long v = tuning().inv_c; v >= 2 && v <= 1024) len = (int)v;  // tuning / tests
         p.c[p.levels] = len;
         p.count[p.levels + 1] = (c + len - 1) / len;   // chains of `len` elements, see k_binv_up
         p.levels++;
@@ -148,7 +172,7 @@ int elementwise_dev(const fpgpu_ctx* ctx, const void* a, const void* b, void* ou
     if (OP == OP_MUL || OP == OP_ADD || OP == OP_SUB) CHECK(check_ptr(ctx, b, "b"));
     CHECK(check_ptr(ctx, out, "out"));
     hipStream_t s = (hipStream_t)stream;
-    DISPATCH_N64(ctx->n64, Launch<N>::elementwise(OP, ctx, a, b, out, n, s));
+    DISPATCH_N64(ctx->n64, HIP_TRY(Launch<N>::elementwise(OP, ctx, a, b, out, n, s)));
     HIP_TRY(hipGetLastError());
     return FPGPU_OK;
 }
@@ -269,7 +293,7 @@ int fpgpu_mul_chain_dev(const fpgpu_ctx* ctx, const void* a, const void* b, void
     CHECK(check_ptr(ctx, b, "b"));
     CHECK(check_ptr(ctx, out, "out"));
     hipStream_t s = (hipStream_t)stream;
-    DISPATCH_N64(ctx->n64, Launch<N>::mul_chain(ctx, a, b, out, n, iters, s));
+    DISPATCH_N64(ctx->n64, HIP_TRY(Launch<N>::mul_chain(ctx, a, b, out, n, iters, s)));
     HIP_TRY(hipGetLastError());
     return FPGPU_OK;
 }
@@ -290,7 +314,7 @@ int fpgpu_batch_inv_dev(const fpgpu_ctx* ctx, const void* x, void* out, uint8_t*
     if (workspace_bytes < fpgpu_batch_inv_workspace_bytes(ctx, n))
         return fail(FPGPU_ERR_SHAPE, "batch_inv: workspace too small");
     hipStream_t s = (hipStream_t)stream;
-    DISPATCH_N64(ctx->n64, Launch<N>::batch_inv(ctx, x, out, zero_flags, n, (char*)workspace, s));
+    DISPATCH_N64(ctx->n64, HIP_TRY(Launch<N>::batch_inv(ctx, x, out, zero_flags, n, (char*)workspace, s)));
     HIP_TRY(hipGetLastError());
     return FPGPU_OK;
 }
@@ -313,7 +337,7 @@ int fpgpu_matvec_dev(const fpgpu_ctx* ctx, const void* A, size_t rows, size_t co
         CHECK(check_ptr(ctx, x, "x"));
     }
     hipStream_t s = (hipStream_t)stream;
-    DISPATCH_N64(ctx->n64, Launch<N>::matvec(ctx, A, rows, cols, x, y, workspace, workspace_bytes, s));
+    DISPATCH_N64(ctx->n64, HIP_TRY(Launch<N>::matvec(ctx, A, rows, cols, x, y, workspace, workspace_bytes, s)));
     HIP_TRY(hipGetLastError());
     return FPGPU_OK;
 }
@@ -331,7 +355,7 @@ int fpgpu_spmv_dev(const fpgpu_ctx* ctx, const void* vals, const uint32_t* col_i
         if (cols) CHECK(check_ptr(ctx, x, "x"));
     }
     hipStream_t s = (hipStream_t)stream;
-    DISPATCH_N64(ctx->n64, Launch<N>::spmv(ctx, vals, col_idx, rows, cols, (uint32_t)density, x, y, s));
+    DISPATCH_N64(ctx->n64, HIP_TRY(Launch<N>::spmv(ctx, vals, col_idx, rows, cols, (uint32_t)density, x, y, s)));
     HIP_TRY(hipGetLastError());
     return FPGPU_OK;
 }
@@ -355,7 +379,7 @@ int fpgpu_matmul_dev(const fpgpu_ctx* ctx, const void* A, const void* B, void* C
     size_t gx = (n + kMMTile - 1) / kMMTile, gy = (m + kMMTile - 1) / kMMTile;
     if (gy > 65535 || gx > ((size_t)1 << 31) - 1) return fail(FPGPU_ERR_SHAPE, "matrix too large");
     hipStream_t s = (hipStream_t)stream;
-    DISPATCH_N64(ctx->n64, Launch<N>::matmul(ctx, A, B, C, m, k, n, workspace, workspace_bytes, s));
+    DISPATCH_N64(ctx->n64, HIP_TRY(Launch<N>::matmul(ctx, A, B, C, m, k, n, workspace, workspace_bytes, s)));
     HIP_TRY(hipGetLastError());
     return FPGPU_OK;
 }
@@ -376,7 +400,7 @@ int fpgpu_pow_dev(const fpgpu_ctx* ctx, const void* a, const uint64_t* exponent_
         if (exponent_le[i]) top = 64 * (int)i + 63 - __builtin_clzll(exponent_le[i]);
     }
     hipStream_t s = (hipStream_t)stream;
-    DISPATCH_N64(ctx->n64, Launch<N>::pow(ctx, a, e32, top, out, n, s));
+    DISPATCH_N64(ctx->n64, HIP_TRY(Launch<N>::pow(ctx, a, e32, top, out, n, s)));
     HIP_TRY(hipGetLastError());
     return FPGPU_OK;
 }
@@ -401,7 +425,7 @@ static int fold_dev(bool product, const fpgpu_ctx* ctx, const void* v, size_t n,
         if (!workspace || (uintptr_t)workspace % 16) return fail(FPGPU_ERR_SHAPE, "fold: workspace null or misaligned");
         if (workspace_bytes < fpgpu_fold_workspace_bytes(ctx)) return fail(FPGPU_ERR_SHAPE, "fold: workspace too small");
     }
-    DISPATCH_N64(ctx->n64, Launch<N>::fold(product, ctx, v, n, out, workspace, s));
+    DISPATCH_N64(ctx->n64, HIP_TRY(Launch<N>::fold(product, ctx, v, n, out, workspace, s)));
     HIP_TRY(hipGetLastError());
     return FPGPU_OK;
 }
@@ -419,7 +443,7 @@ int fpgpu_fill_random_dev(const fpgpu_ctx* ctx, void* out, size_t n, uint64_t se
     if (n == 0) return FPGPU_OK;
     CHECK(check_ptr(ctx, out, "out"));
     hipStream_t s = (hipStream_t)stream;
-    DISPATCH_N64(ctx->n64, Launch<N>::fill_random(ctx, out, n, seed, s));
+    DISPATCH_N64(ctx->n64, HIP_TRY(Launch<N>::fill_random(ctx, out, n, seed, s)));
     HIP_TRY(hipGetLastError());
     return FPGPU_OK;
 }
@@ -579,6 +603,17 @@ int fpgpu_matmul(const fpgpu_ctx* ctx, const uint64_t* A, const uint64_t* B, uin
     HIP_TRY(hipStreamSynchronize(nullptr));
     HIP_TRY(hipMemcpy(C, dC.p, m * n * esz, hipMemcpyDeviceToHost));
     return FPGPU_OK;
+}
+
+int fpgpu_tuning_set(const char* name, long value) {
+    if (!name) return fail(FPGPU_ERR_SHAPE, "null pointer: name");
+    Tuning& t = tuning_mutable();
+    for (const TuningEntry& e : kTuningEntries)
+        if (std::strcmp(name, e.name) == 0) {
+            t.*(e.field) = value == FPGPU_TUNING_DEFAULT ? g_tuning_defaults.*(e.field) : value;
+            return FPGPU_OK;
+        }
+    return fail(FPGPU_ERR_UNSUPPORTED, std::string("unknown tuning hook: ") + name);
 }
 
 const char* fpgpu_last_error_string(void) { return g_last_error.c_str(); }

@@ -175,6 +175,16 @@ int fpgpu_spmv(const fpgpu_ctx *ctx, const uint64_t *vals, const uint32_t *col_i
 int fpgpu_matmul(const fpgpu_ctx *ctx, const uint64_t *A, const uint64_t *B, uint64_t *C, size_t m,
                  size_t k, size_t n);
 
+/* ---- tuning / test hooks -----------------------------------------------------
+ * No counterpart in the reference.  The hooks of INTEGRATION.md section 4 (FPGPU_GRID_CAP,
+ * FPGPU_INV_C, FPGPU_MATVEC_MFMA, FPGPU_MATVEC_KSPLIT, FPGPU_MATVEC_T, FPGPU_MATMUL_MFMA,
+ * FPGPU_MATMUL_GENERIC, FPGPU_SPMV_LOG2G) are read from the environment once, when the library
+ * is first used; this call sets one afterwards (process-wide; FPGPU_TUNING_DEFAULT restores the
+ * library's choice).  No hook changes a result -- they pick between bit-identical paths.  Not
+ * synchronised against calls running on other threads. */
+#define FPGPU_TUNING_DEFAULT (-0x7fffffffL - 1)
+int fpgpu_tuning_set(const char *name, long value);
+
 /* ---- diagnostics ----------------------------------------------------------- */
 const char *fpgpu_last_error_string(void); /* thread-local, never NULL */
 int fpgpu_device_count(void);              /* gfx950 devices visible to this process */

@@ -4,7 +4,7 @@
 #![no_std]
 #![allow(non_camel_case_types)]
 
-use core::ffi::{c_char, c_int, c_void};
+use core::ffi::{c_char, c_int, c_long, c_void};
 
 /// Opaque `fpgpu_ctx`: immutable after creation, shareable between threads.
 #[repr(C)]
@@ -21,6 +21,7 @@ pub const FPGPU_ERR_HIP: c_int = 4;
 /// No gfx950 device visible: there is no CPU fallback.
 pub const FPGPU_ERR_NO_DEVICE: c_int = 5;
 pub const FPGPU_MAX_N64: u32 = 8;
+pub const FPGPU_TUNING_DEFAULT: c_long = -0x7fff_ffff - 1;
 
 extern "C" {
     // ---- field configuration
@@ -89,6 +90,9 @@ extern "C" {
     pub fn fpgpu_spmv(ctx: *const fpgpu_ctx, vals: *const u64, col_idx: *const u32, rows: usize, cols: usize,
                       density: usize, x: *const u64, y: *mut u64) -> c_int;
     pub fn fpgpu_matmul(ctx: *const fpgpu_ctx, a: *const u64, b: *const u64, c: *mut u64, m: usize, k: usize, n: usize) -> c_int;
+
+    // ---- tuning / test hooks (process-wide; FPGPU_TUNING_DEFAULT restores the default)
+    pub fn fpgpu_tuning_set(name: *const c_char, value: c_long) -> c_int;
 
     // ---- diagnostics
     pub fn fpgpu_last_error_string() -> *const c_char;

@@ -72,3 +72,19 @@ def synth_elements(p, n64, n, seed):
 @pytest.fixture(params=FIELD_NAMES)
 def golden(request):
     return load_golden(request.param)
+
+
+@pytest.fixture
+def tuning():
+    """Sets tuning / test hooks of the library (fpgpu_tuning_set) and restores the defaults afterwards.
+    The library reads the FPGPU_* environment once, at first use, so tests go through this instead."""
+    from crypto_primitives_amd import _lib
+    touched = []
+
+    def set_hook(name, value):
+        touched.append(name)
+        _lib.tuning_set(name, int(value))
+
+    yield set_hook
+    for name in touched:
+        _lib.tuning_set(name)

@@ -97,7 +97,7 @@ def test_rust_sys_crate_binds_every_declared_symbol():
         assert nargs(c_decl[name]) == nargs(r_decl[name]), name
 
 
-def test_batch_inv_workspace_plan_is_sane(monkeypatch):
+def test_batch_inv_workspace_plan_is_sane(tuning):
     """Host arithmetic of the inversion plan: the workspace grows with n, stays a small fraction of
     the batch for the default chain lengths, and follows the FPGPU_INV_C tuning hook."""
     lib = cpa.load()
@@ -105,9 +105,11 @@ def test_batch_inv_workspace_plan_is_sane(monkeypatch):
     sizes = [lib.fpgpu_batch_inv_workspace_bytes(f._h, n) for n in (1, 2, 255, 256, 257, 70001, 1 << 20, 1 << 24)]
     assert all(a <= b for a, b in zip(sizes, sizes[1:])) and sizes[0] > 0
     assert sizes[-1] < (1 << 24) * 48 // 8          # chains of 32 at the big level: totals are n/32 elements
-    monkeypatch.setenv("FPGPU_INV_C", "2")
+    tuning("FPGPU_INV_C", 2)
     assert lib.fpgpu_batch_inv_workspace_bytes(f._h, 1 << 20) > (1 << 20) * 48 // 2
     assert lib.fpgpu_batch_inv_workspace_bytes(f._h, 0) == 0
+    # an unknown hook is an error, not a silent no-op
+    assert lib.fpgpu_tuning_set(b"FPGPU_NO_SUCH_HOOK", 1) == _lib.ERR_UNSUPPORTED
 
 
 def test_spmv_argument_checks_need_no_gpu():

@@ -180,10 +180,10 @@ def test_batch_inv_vs_oracle(cpa, n):
 
 
 @pytest.mark.parametrize("clen", ["2", "3", "32", "100"])
-def test_batch_inv_chain_lengths(cpa, clen, monkeypatch):
+def test_batch_inv_chain_lengths(cpa, clen, tuning):
     """The chain length per level is a tuning choice (FPGPU_INV_C pins it): every partition into
     chains gives the same inverses, ragged last chains and many levels included."""
-    monkeypatch.setenv("FPGPU_INV_C", clen)
+    tuning("FPGPU_INV_C", clen)
     for name, n in (("bls12_381_fq", 70001), ("bn254_fr", 40000), ("goldilocks", 100003), ("odd_composite_128", 6000)):
         g = load_golden(name)
         p, n64 = h2i(g["modulus"]), g["n64"]
@@ -252,11 +252,11 @@ def test_matvec_vs_oracle(cpa, shape):
 
 
 @pytest.mark.parametrize("T", ["2", "4"])
-def test_matvec_multi_term_passes(cpa, T, monkeypatch):
+def test_matvec_multi_term_passes(cpa, T, tuning):
     """The T-products-per-pass mat-vec variants (selected with FPGPU_MATVEC_T; T = 1 is the
     default) must give the same canonical residues; moduli without headroom fall back to
     T = 1 inside the library."""
-    monkeypatch.setenv("FPGPU_MATVEC_T", T)
+    tuning("FPGPU_MATVEC_T", T)
     for name in ("bn254_fr", "bls12_381_fq", "bench_120bit", "secp256k1_p", "goldilocks"):
         g = load_golden(name)
         p, n64 = h2i(g["modulus"]), g["n64"]
@@ -348,7 +348,7 @@ def test_matvec_matrix_core_path_vs_oracle(cpa, shape):
             assert np.array_equal(got.reshape(want.shape), want), (name, mode, "valu")
 
 
-def test_matvec_matrix_core_int32_flush_and_column_split(cpa, monkeypatch):
+def test_matvec_matrix_core_int32_flush_and_column_split(cpa, tuning):
     """One column part per row block (forced) so that the int32 tiles are flushed inside the loop
     (every 255 chunks = 4080 elements), then the default split over many workgroups; extreme bytes."""
     g = load_golden("bn254_fr")
@@ -361,10 +361,7 @@ def test_matvec_matrix_core_int32_flush_and_column_split(cpa, monkeypatch):
         x = ints_to_array([vx] * cols, n64)
         want = o.matvec(A, rows, cols, x, threads=0)
         for ks in ("1", "3", None):
-            if ks is None:
-                monkeypatch.delenv("FPGPU_MATVEC_KSPLIT", raising=False)
-            else:
-                monkeypatch.setenv("FPGPU_MATVEC_KSPLIT", ks)
+            tuning("FPGPU_MATVEC_KSPLIT", 0 if ks is None else ks)
             got = _dev_matvec(cpa, f, A, rows, cols, x, True)
             assert np.array_equal(got.reshape(want.shape), want), (hex(va), hex(vx), ks)
 
@@ -656,12 +653,12 @@ def test_empty_dimensions(cpa):
 
 
 @pytest.mark.parametrize("hook", ["FPGPU_MATMUL_GENERIC=1", "FPGPU_MATMUL_MFMA=0", "FPGPU_MATVEC_MFMA=0"])
-def test_forced_kernel_paths_agree(cpa, hook, monkeypatch):
+def test_forced_kernel_paths_agree(cpa, hook, tuning):
     """The path-forcing hooks of INTEGRATION.md section 4: single-limb mat-mul through the multi-limb
     kernel and through the VALU kernel, mat-vec through the VALU kernel although a workspace is
     given - all bit-identical to the oracle."""
     name, val = hook.split("=")
-    monkeypatch.setenv(name, val)
+    tuning(name, val)
     for gname in ("goldilocks", "p64_ref_tests", "bn254_fr"):
         g = load_golden(gname)
         p, n64 = h2i(g["modulus"]), g["n64"]
