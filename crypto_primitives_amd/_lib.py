@@ -31,6 +31,8 @@ SIGNATURES = {
     "fpgpu_mul_chain_dev": (_int, [_vp, _vp, _vp, _vp, _sz, _u32, _vp]),
     "fpgpu_batch_inv_workspace_bytes": (_sz, [_vp, _sz]),
     "fpgpu_batch_inv_dev": (_int, [_vp, _vp, _vp, _vp, _sz, _vp, _sz, _vp]),
+    "fpgpu_static_scratch_bytes": (_sz, []),
+    "fpgpu_batch_inv_static_dev": (_int, [_vp, _vp, _vp, _vp, _sz, _vp]),
     "fpgpu_matvec_workspace_bytes": (_sz, [_vp, _sz, _sz]),
     "fpgpu_matvec_dev": (_int, [_vp, _vp, _sz, _sz, _vp, _vp, _vp, _sz, _vp]),
     "fpgpu_spmv_dev": (_int, [_vp, _vp, _vp, _sz, _sz, _sz, _vp, _vp, _vp]),

@@ -66,6 +66,37 @@ uint64_t neg_inv64(uint64_t m0) {
     return 0 - inv;
 }
 
+
+// ---- static device scratch of fpgpu_batch_inv_static_dev -------------------------------
+// Workspace of the batch inversion for callers that cannot allocate (HIP graph capture,
+// serving loops): a file-scope device array, one copy per GPU at its own address, held until
+// the process ends.  Host code never uses the array's name as an address: the per-device
+// pointer comes from hipGetSymbolAddress, once per device, and is what the kernels receive.
+static __device__ __align__(256) unsigned char g_static_scratch[FPGPU_STATIC_SCRATCH_BYTES];
+constexpr int kMaxDevices = 64;
+std::mutex g_static_scratch_mutex;
+void* g_static_scratch_ptr[kMaxDevices] = {nullptr};
+
+// Device address of g_static_scratch on the CURRENT device (looked up on the first call there).
+int static_scratch_for_current_device(void** out) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(FPGPU_ERR_NO_DEVICE, "no HIP device visible: libfpgpu has no CPU fallback");
+    }
+    if (dev < 0 || dev >= kMaxDevices) return fail(FPGPU_ERR_UNSUPPORTED, "device index beyond the static scratch table");
+    std::lock_guard<std::mutex> lock(g_static_scratch_mutex);
+    if (!g_static_scratch_ptr[dev]) {
+        void* p = nullptr;
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(g_static_scratch));
+        if (e != hipSuccess || !p) return hip_fail(e, "hipGetSymbolAddress(g_static_scratch)");
+        g_static_scratch_ptr[dev] = p;
+    }
+    *out = g_static_scratch_ptr[dev];
+    return FPGPU_OK;
+}
+
 }  // namespace
 
 namespace fpgpu {
@@ -315,6 +346,31 @@ int fpgpu_batch_inv_dev(const fpgpu_ctx* ctx, const void* x, void* out, uint8_t*
         return fail(FPGPU_ERR_SHAPE, "batch_inv: workspace too small");
     hipStream_t s = (hipStream_t)stream;
     DISPATCH_N64(ctx->n64, HIP_TRY(Launch<N>::batch_inv(ctx, x, out, zero_flags, n, (char*)workspace, s)));
+    HIP_TRY(hipGetLastError());
+    return FPGPU_OK;
+}
+
+size_t fpgpu_static_scratch_bytes(void) { return FPGPU_STATIC_SCRATCH_BYTES; }
+
+int fpgpu_batch_inv_static_dev(const fpgpu_ctx* ctx, const void* x, void* out, uint8_t* zero_flags, size_t n,
+                               void* stream) {
+    CHECK(check_common(ctx, n));
+    if (n == 0) return FPGPU_OK;
+    CHECK(check_ptr(ctx, x, "x"));
+    CHECK(check_ptr(ctx, out, "out"));
+    if (x == out) return fail(FPGPU_ERR_SHAPE, "batch_inv: out must not alias x");
+    const size_t need = fpgpu_batch_inv_workspace_bytes(ctx, n);
+    if (need > (size_t)FPGPU_STATIC_SCRATCH_BYTES)
+        return fail(FPGPU_ERR_SHAPE, "batch_inv_static: " + std::to_string(n) + " elements need " + std::to_string(need) +
+                                         " bytes of scratch, the static array holds " +
+                                         std::to_string((size_t)FPGPU_STATIC_SCRATCH_BYTES) +
+                                         " (use fpgpu_batch_inv_dev with a caller workspace)");
+    void* scratch = nullptr;
+    CHECK(static_scratch_for_current_device(&scratch));
+    hipStream_t s = (hipStream_t)stream;
+    // the launcher clears what must start at zero (the poison word); everything else in the
+    // scratch is written before it is read, so the previous call's contents do not matter
+    DISPATCH_N64(ctx->n64, HIP_TRY(Launch<N>::batch_inv(ctx, x, out, zero_flags, n, (char*)scratch, s)));
     HIP_TRY(hipGetLastError());
     return FPGPU_OK;
 }

@@ -229,6 +229,13 @@ class MontyField:
                                             self._stream()))
         return out
 
+    def inv_static_dev(self, x, out, flags):
+        """fpgpu_batch_inv_static_dev: batch inversion that allocates nothing and takes no workspace (the
+        library's static device array); same results as inv_dev."""
+        fp = ctypes.c_void_p(flags.data_ptr()) if flags is not None else None
+        check(self._lib.fpgpu_batch_inv_static_dev(self._h, self._chk_t(x), self._chk_t(out), fp, x.shape[0], self._stream()))
+        return out
+
     def matvec_workspace_bytes(self, rows, cols):
         return int(self._lib.fpgpu_matvec_workspace_bytes(self._h, rows, cols))
 

@@ -119,6 +119,21 @@ size_t fpgpu_batch_inv_workspace_bytes(const fpgpu_ctx *ctx, size_t n);
 int fpgpu_batch_inv_dev(const fpgpu_ctx *ctx, const void *x, void *out, uint8_t *zero_flags, size_t n,
                         void *workspace, size_t workspace_bytes, void *stream);
 
+/* Batch inversion that allocates nothing and takes no workspace.  NO COUNTERPART IN THE
+ * REFERENCE: it exists for callers that cannot allocate device memory or carry a workspace --
+ * code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  Same
+ * results and flags as fpgpu_batch_inv_dev; the workspace is a static device array of
+ * FPGPU_STATIC_SCRATCH_BYTES inside the library (one copy per GPU, held until the process ends).
+ * A batch whose fpgpu_batch_inv_workspace_bytes(ctx, n) exceeds that returns FPGPU_ERR_SHAPE
+ * (64 MiB covers 2^24 384-bit elements).  Every call on a GPU uses that GPU's one array: calls that
+ * overlap on the same GPU (different streams or threads) race; calls in stream order do not.
+ * The array's device address is looked up on the first call on each device (not an allocation;
+ * make that first call outside graph capture). */
+#define FPGPU_STATIC_SCRATCH_BYTES (64u << 20)
+size_t fpgpu_static_scratch_bytes(void);
+int fpgpu_batch_inv_static_dev(const fpgpu_ctx *ctx, const void *x, void *out, uint8_t *zero_flags, size_t n,
+                               void *stream);
+
 /* ---- dense matrix products over DenseRowMatrix<T> (src/matrix.rs:135-164) --
  * y[i] = sum_j mul(A[i*cols + j], x[j]): the SemiringConfig::sum_refs fold
  * (src/semiring.rs:213-226) of monty_mul over DenseRowMatrix::as_rows().

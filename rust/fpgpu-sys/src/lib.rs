@@ -21,6 +21,7 @@ pub const FPGPU_ERR_HIP: c_int = 4;
 /// No gfx950 device visible: there is no CPU fallback.
 pub const FPGPU_ERR_NO_DEVICE: c_int = 5;
 pub const FPGPU_MAX_N64: u32 = 8;
+pub const FPGPU_STATIC_SCRATCH_BYTES: usize = 64 << 20;
 pub const FPGPU_TUNING_DEFAULT: c_long = -0x7fff_ffff - 1;
 
 extern "C" {
@@ -58,6 +59,11 @@ extern "C" {
     pub fn fpgpu_batch_inv_workspace_bytes(ctx: *const fpgpu_ctx, n: usize) -> usize;
     pub fn fpgpu_batch_inv_dev(ctx: *const fpgpu_ctx, x: *const c_void, out: *mut c_void, zero_flags: *mut u8, n: usize,
                                workspace: *mut c_void, workspace_bytes: usize, stream: *mut c_void) -> c_int;
+    /// No counterpart in the reference: batch inversion for callers that cannot allocate (HIP graph
+    /// capture, serving loops); the workspace is a static device array of `FPGPU_STATIC_SCRATCH_BYTES`.
+    pub fn fpgpu_static_scratch_bytes() -> usize;
+    pub fn fpgpu_batch_inv_static_dev(ctx: *const fpgpu_ctx, x: *const c_void, out: *mut c_void, zero_flags: *mut u8,
+                                      n: usize, stream: *mut c_void) -> c_int;
 
     // ---- matrix products
     pub fn fpgpu_matvec_workspace_bytes(ctx: *const fpgpu_ctx, rows: usize, cols: usize) -> usize;

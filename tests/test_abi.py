@@ -112,6 +112,21 @@ def test_batch_inv_workspace_plan_is_sane(tuning):
     assert lib.fpgpu_tuning_set(b"FPGPU_NO_SUCH_HOOK", 1) == _lib.ERR_UNSUPPORTED
 
 
+def test_static_scratch_entry_point_argument_checks():
+    """fpgpu_batch_inv_static_dev: sizes beyond the static array are rejected with a clear error
+    before anything touches a device; n == 0 is a no-op."""
+    lib = cpa.load()
+    f = cpa.MontyField(cpa.BLS12_381_FQ, 6)
+    cap = lib.fpgpu_static_scratch_bytes()
+    assert cap == 64 << 20
+    assert lib.fpgpu_batch_inv_workspace_bytes(f._h, 1 << 24) <= cap      # BASELINE configs[2] fits
+    assert lib.fpgpu_batch_inv_static_dev(f._h, None, None, None, 0, None) == _lib.OK
+    big = 1 << 27
+    assert lib.fpgpu_batch_inv_workspace_bytes(f._h, big) > cap
+    rc = lib.fpgpu_batch_inv_static_dev(f._h, ctypes.c_void_p(256), ctypes.c_void_p(512), None, big, None)
+    assert rc == _lib.ERR_SHAPE and b"static array holds" in lib.fpgpu_last_error_string()
+
+
 def test_spmv_argument_checks_need_no_gpu():
     lib = cpa.load()
     f = cpa.MontyField(cpa.BN254_FR, 4)
