@@ -116,6 +116,18 @@ __device__ __forceinline__ bool mf_tile_of(uint32_t b, uint32_t rblocks, uint32_
 #define MF_LDS_READ(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:" #OFF : "=v"(DST) : "v"(ADDR) : "memory")
 #define MF_WAIT_LGKM(CNT) asm volatile("s_waitcnt lgkmcnt(" #CNT ")" ::: "memory")
 
+// The three places where a timing-only build may alter the main loop (tools/variants/matmul_timing.hpp,
+// force-included by tools/build_variant.sh; such builds give wrong results and are never shipped).
+// The library itself only ever sees these definitions.
+#ifndef MF_STAGE
+#define MF_STAGE(J) stage_part(ks_next, (ks + 1) & 1, J)
+#endif
+#ifndef MF_KSTEPS
+#define MF_KSTEPS(n) (n)
+#endif
+#ifndef MF_KSTEP_BARRIER
+#define MF_KSTEP_BARRIER() __syncthreads()
+#endif
 template <int N>  // N == 2 only (see k_matmul_1limb)
 __global__ __launch_bounds__(256) void k_matmul_mfma_1limb(const uint8_t* __restrict__ Aw, const uint8_t* __restrict__ Bw,
                                                            uint2* __restrict__ Cm, size_t m, size_t n, uint32_t rblocks,
@@ -159,31 +171,15 @@ __global__ __launch_bounds__(256) void k_matmul_mfma_1limb(const uint8_t* __rest
 #pragma unroll
     for (int q = 0; q < 8; q++) stage_part(0, 0, q);
     __syncthreads();  // (waits for this wave's DMAs, then the barrier)
-#ifdef MF_DBG_ONEK  // (timing of the per-tile prologue + epilogue alone)
-    for (uint32_t ks = 0; ks < 1; ks++) {
-#else
-    for (uint32_t ks = 0; ks < ksteps; ks++) {
-#endif
+    for (uint32_t ks = 0; ks < MF_KSTEPS(ksteps); ks++) {
         // the next k-step's DMAs are issued from inside the MFMA stream, two per digit of B; the
         // last k-step re-stages itself into the idle buffer so that no branch is needed
         const uint32_t ks_next = ks + 1 < ksteps ? ks + 1 : ks;
         mf_v4i a[2][8], b[2][2];  // b: [parity of digit j][column tile], read one digit ahead
         const uint32_t a_addr = lds_addr + (ks & 1) * 2 * kMF_CHUNK + lane_off + 2 * wr * 1024;
         const uint32_t b_addr = lds_addr + (ks & 1) * 2 * kMF_CHUNK + kMF_CHUNK + lane_off + 2 * wc * 1024;
-#ifdef MF_DBG_NOSTAGE  // (MF_DBG_*: timing experiments only, results are wrong; tools/build_variant.sh)
-#define MF_STAGE(J)
-#elif defined(MF_DBG_SAMEK)
-#define MF_STAGE(J) stage_part(0, (ks + 1) & 1, J)
-#elif defined(MF_DBG_HALFSTAGE)
-#define MF_STAGE(J) if ((J) & 1) stage_part(ks_next, (ks + 1) & 1, J)
-#else
-#define MF_STAGE(J) stage_part(ks_next, (ks + 1) & 1, J)
-#endif
 #include "fp_matmul_kstep.inc"
-#undef MF_STAGE
-#ifndef MF_DBG_NOBARRIER
-        __syncthreads();  // next buffer has landed (vmcnt(0) per wave) and this one is free to refill
-#endif
+        MF_KSTEP_BARRIER();  // next buffer has landed (vmcnt(0) per wave) and this one is free to refill
     }
     // the compiler does not see the asm MFMAs' writes: cover the MFMA-write -> accvgpr-read hazard by hand
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");

@@ -6,7 +6,7 @@ set -e
 cd "$(dirname "$0")/../crypto_primitives_amd"
 make -s -j8
 NAME=$1; FLAGS=$2; LIMBS=${3:-2}
-HF="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function"
+HF="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -include ../tools/variants/matmul_timing.hpp"
 OBJS=""
 for n in 2 4 6 8 10 12 14 16; do
   if [[ " $LIMBS " == *" $n "* ]]; then
