@@ -10,7 +10,8 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FPGPU_LIB") or os.path.join(_HERE, "libfpgpu.so")  # FPGPU_LIB: tuning builds
 
-OK, ERR_INVALID_MODULUS, ERR_UNSUPPORTED, ERR_SHAPE, ERR_HIP, ERR_NO_DEVICE = range(6)
+OK, ERR_INVALID_MODULUS, ERR_UNSUPPORTED, ERR_SHAPE, ERR_HIP, ERR_NO_DEVICE, ERR_RCCL = range(7)
+PLACE_CURRENT, PLACE_SHARDED, PLACE_REPLICATED = -1, -2, -3
 
 _c = ctypes
 _vp, _sz, _u32, _u64, _int = _c.c_void_p, _c.c_size_t, _c.c_uint32, _c.c_uint64, _c.c_int
@@ -58,6 +59,37 @@ SIGNATURES = {
     "fpgpu_batch_inv": (_int, [_vp, _vp, _vp, _vp, _sz]),
     "fpgpu_matvec": (_int, [_vp, _vp, _sz, _sz, _vp, _vp]),
     "fpgpu_matmul": (_int, [_vp, _vp, _vp, _vp, _sz, _sz, _sz]),
+    "fpgpu_dot_dev": (_int, [_vp, _vp, _vp, _sz, _vp, _vp, _sz, _vp]),
+    "fpgpu_dot": (_int, [_vp, _vp, _vp, _sz, _vp]),
+    "fpgpu_set_devices": (_int, [_c.POINTER(_int), _int]),
+    "fpgpu_get_devices": (_int, [_c.POINTER(_int), _int]),
+    "fpgpu_vec_alloc": (_int, [_vp, _sz, _int, _c.POINTER(_vp)]),
+    "fpgpu_vec_alloc_rows": (_int, [_vp, _sz, _sz, _int, _c.POINTER(_vp)]),
+    "fpgpu_vec_free": (None, [_vp]),
+    "fpgpu_vec_len": (_sz, [_vp]),
+    "fpgpu_vec_parts": (_int, [_vp]),
+    "fpgpu_vec_part": (_int, [_vp, _int, _c.POINTER(_int), _c.POINTER(_sz), _c.POINTER(_sz), _c.POINTER(_vp),
+                              _c.POINTER(_vp)]),
+    "fpgpu_vec_upload": (_int, [_vp, _vp, _sz, _sz]),
+    "fpgpu_vec_download": (_int, [_vp, _vp, _sz, _sz]),
+    "fpgpu_vec_sync": (_int, [_vp]),
+    "fpgpu_vec_copy": (_int, [_vp, _vp]),
+    "fpgpu_vec_fill_random": (_int, [_vp, _vp, _u64]),
+    "fpgpu_vec_mul": (_int, [_vp, _vp, _vp, _vp]),
+    "fpgpu_vec_sqr": (_int, [_vp, _vp, _vp]),
+    "fpgpu_vec_add": (_int, [_vp, _vp, _vp, _vp]),
+    "fpgpu_vec_sub": (_int, [_vp, _vp, _vp, _vp]),
+    "fpgpu_vec_neg": (_int, [_vp, _vp, _vp]),
+    "fpgpu_vec_to_mont": (_int, [_vp, _vp, _vp]),
+    "fpgpu_vec_from_mont": (_int, [_vp, _vp, _vp]),
+    "fpgpu_vec_mul_chain": (_int, [_vp, _vp, _vp, _vp, _u32]),
+    "fpgpu_vec_pow": (_int, [_vp, _vp, _vp, _u32, _vp]),
+    "fpgpu_vec_batch_inv": (_int, [_vp, _vp, _vp, _vp, _c.POINTER(_sz)]),
+    "fpgpu_vec_sum": (_int, [_vp, _vp, _vp]),
+    "fpgpu_vec_product": (_int, [_vp, _vp, _vp]),
+    "fpgpu_vec_dot": (_int, [_vp, _vp, _vp, _vp]),
+    "fpgpu_vec_matvec": (_int, [_vp, _vp, _sz, _sz, _vp, _vp]),
+    "fpgpu_vec_matmul": (_int, [_vp, _vp, _vp, _vp, _sz, _sz, _sz]),
     "fpgpu_tuning_set": (_int, [_c.c_char_p, _c.c_long]),
     "fpgpu_last_error_string": (_c.c_char_p, []),
     "fpgpu_device_count": (_int, []),

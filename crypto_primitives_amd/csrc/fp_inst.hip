@@ -216,8 +216,9 @@ hipError_t Launch<N>::matmul(const fpgpu_ctx* ctx, const void* A, const void* B,
 }
 
 template <int N>
-hipError_t Launch<N>::fill_random(const fpgpu_ctx* ctx, void* out, size_t n, uint64_t seed, hipStream_t s) {
-    hipLaunchKernelGGL((k_fill_random<N>), dim3(grid_for(n)), dim3(kBlock), 0, s, (uint32_t*)out, n, seed,
+hipError_t Launch<N>::fill_random(const fpgpu_ctx* ctx, void* out, size_t n, uint64_t seed, size_t first,
+                                  hipStream_t s) {
+    hipLaunchKernelGGL((k_fill_random<N>), dim3(grid_for(n)), dim3(kBlock), 0, s, (uint32_t*)out, n, seed, first,
                        make_params<N>(ctx));
     return hipSuccess;
 }
@@ -268,6 +269,22 @@ hipError_t Launch<N>::fold(bool product, const fpgpu_ctx* ctx, const void* v, si
         if (product) hipLaunchKernelGGL((k_fold<N, true>), dim3(1), dim3(kBlock), 0, s, (const uint32_t*)ws, blocks, (uint32_t*)out, P);
         else hipLaunchKernelGGL((k_fold<N, false>), dim3(1), dim3(kBlock), 0, s, (const uint32_t*)ws, blocks, (uint32_t*)out, P);
     }
+    return hipSuccess;
+}
+
+template <int N>
+hipError_t Launch<N>::dot(const fpgpu_ctx* ctx, const void* a, const void* b, size_t n, void* out, void* ws,
+                          hipStream_t s) {
+    size_t blocks = (n + kBlock - 1) / kBlock;
+    if (blocks > (size_t)kFoldBlocks) blocks = kFoldBlocks;
+    if (blocks < 1) blocks = 1;
+    const FpParams<N> P = make_params<N>(ctx);
+    // pass 1: one canonical partial per workgroup (straight to `out` when one workgroup covers everything)
+    uint32_t* p1 = blocks == 1 ? (uint32_t*)out : (uint32_t*)ws;
+    hipLaunchKernelGGL((k_dot<N>), dim3((unsigned)blocks), dim3(kBlock), 0, s, (const uint32_t*)a, (const uint32_t*)b, n,
+                       p1, P);
+    if (blocks > 1)
+        hipLaunchKernelGGL((k_fold<N, false>), dim3(1), dim3(kBlock), 0, s, (const uint32_t*)ws, blocks, (uint32_t*)out, P);
     return hipSuccess;
 }
 

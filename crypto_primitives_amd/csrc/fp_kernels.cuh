@@ -103,13 +103,14 @@ __device__ __forceinline__ uint64_t splitmix64(uint64_t z) {
 }
 template <int N>
 __global__ __launch_bounds__(kBlock) void k_fill_random(uint32_t* __restrict__ out, size_t n, uint64_t seed,
-                                                        const FpParams<N> P) {
+                                                        size_t first, const FpParams<N> P) {
+    // out[i] is element first + i of the generator's sequence (a shard of a larger vector passes its offset)
     const size_t stride = (size_t)gridDim.x * kBlock;
     for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
         uint32_t x[N], d[N];
 #pragma unroll
         for (int l = 0; l < N / 2; l++) {
-            uint64_t w = splitmix64(seed ^ (i * (N / 2) + l));
+            uint64_t w = splitmix64(seed ^ ((first + i) * (N / 2) + l));
             x[2 * l] = (uint32_t)w;
             x[2 * l + 1] = (uint32_t)(w >> 32);
         }
@@ -773,6 +774,49 @@ __global__ __launch_bounds__(kBlock) void k_fold(const uint32_t* __restrict__ v,
 #pragma unroll
             for (int l = 0; l < N; l++) o[l] = part[w][l];
             fold2<N, PROD>(acc, o, P);
+        }
+        store_elem<N>(partials, blockIdx.x, acc);
+    }
+}
+
+// ---- dot product: sum_i mul(a[i], b[i]), the sum_refs fold of monty_mul
+// (src/semiring.rs:213-226 over helpers::mul::monty_mul) -- one row of the mat-vec, spread over the
+// whole chip.  Lazy reduction exactly as k_matvec: each lane adds its plain 2N-limb products into a
+// wide accumulator kept below p*R and pays one Montgomery reduction at the end; one canonical
+// partial per workgroup, summed by k_fold<N, false>.  Operands must be canonical (< p), as for the
+// mat-vec: the canonical result then equals the reference's left fold.
+template <int N>
+__global__ __launch_bounds__(kBlock) void k_dot(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b,
+                                                size_t n, uint32_t* __restrict__ partials, const FpParams<N> P) {
+    __shared__ uint32_t part[kBlock / 64][N];
+    uint32_t S[2 * N];
+#pragma unroll
+    for (int l = 0; l < 2 * N; l++) S[l] = 0;
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        uint32_t x[1][N], y[1][N], prod[2 * N];
+        load_elem<N>(x[0], a, i);
+        load_elem<N>(y[0], b, i);
+        mul_wide_sum<N, 1>(prod, x, y);
+        wide_acc_add<N>(S, prod, P);
+    }
+    uint32_t acc[N];
+    mont_redc_wide<N>(acc, S, P);
+    wave_reduce_add<N>(acc, P);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) {
+#pragma unroll
+        for (int l = 0; l < N; l++) part[wave][l] = acc[l];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t o[N], t[N];
+        for (int w = 1; w < kBlock / 64; w++) {
+#pragma unroll
+            for (int l = 0; l < N; l++) o[l] = part[w][l];
+            mod_add<N>(t, acc, o, P);
+#pragma unroll
+            for (int l = 0; l < N; l++) acc[l] = t[l];
         }
         store_elem<N>(partials, blockIdx.x, acc);
     }

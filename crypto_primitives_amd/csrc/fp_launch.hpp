@@ -115,6 +115,7 @@ struct Tuning {
     long matmul_mfma = -1;    // FPGPU_MATMUL_MFMA: 0 forces the VALU single-limb mat-mul
     long matmul_generic = 0;  // FPGPU_MATMUL_GENERIC: 1 forces the multi-limb mat-mul kernel
     long spmv_log2g = -1;     // FPGPU_SPMV_LOG2G: log2 of the lanes sharing a sparse row
+    long allgather_copy = 0;  // FPGPU_ALLGATHER_COPY: 1 = peer copies instead of RCCL for the all-gather
 };
 const Tuning& tuning();
 
@@ -134,13 +135,16 @@ struct Launch {
     static hipError_t matmul(const fpgpu_ctx* ctx, const void* A, const void* B, void* C, size_t m, size_t k, size_t n,
                        void* workspace, size_t workspace_bytes,
                        hipStream_t s);
-    static hipError_t fill_random(const fpgpu_ctx* ctx, void* out, size_t n, uint64_t seed, hipStream_t s);
+    static hipError_t fill_random(const fpgpu_ctx* ctx, void* out, size_t n, uint64_t seed, size_t first,
+                                  hipStream_t s);
     static hipError_t spmv(const fpgpu_ctx* ctx, const void* vals, const uint32_t* colidx, size_t rows, size_t cols,
                      uint32_t density, const void* x, void* y, hipStream_t s);
     static hipError_t pow(const fpgpu_ctx* ctx, const void* a, const uint32_t* exp32, int top_bit, void* out, size_t n,
                     hipStream_t s);
     static hipError_t fold(bool product, const fpgpu_ctx* ctx, const void* v, size_t n, void* out, void* ws,
-                     hipStream_t s);
+                           hipStream_t s);
+    static hipError_t dot(const fpgpu_ctx* ctx, const void* a, const void* b, size_t n, void* out, void* ws,
+                          hipStream_t s);
 };
 
 extern template struct Launch<2>;

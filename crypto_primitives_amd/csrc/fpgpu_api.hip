@@ -15,13 +15,12 @@
 #include <vector>
 
 #include "fp_launch.hpp"
+#include "fpgpu_internal.hpp"
 
 using namespace fpgpu;
 
-namespace {
-
+namespace fpgpu {
 thread_local std::string g_last_error = "";
-
 int fail(int code, const std::string& msg) {
     g_last_error = msg;
     return code;
@@ -29,11 +28,9 @@ int fail(int code, const std::string& msg) {
 int hip_fail(hipError_t e, const char* what) {
     return fail(FPGPU_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
 }
-#define HIP_TRY(expr)                                  \
-    do {                                               \
-        hipError_t _e = (expr);                        \
-        if (_e != hipSuccess) return hip_fail(_e, #expr); \
-    } while (0)
+}  // namespace fpgpu
+
+namespace {
 
 // ---- host-side big integers (product code: parameter set-up only) ----------------
 using u128 = unsigned __int128;
@@ -111,6 +108,7 @@ static const TuningEntry kTuningEntries[] = {
     {"FPGPU_MATVEC_MFMA", &Tuning::matvec_mfma},   {"FPGPU_MATVEC_KSPLIT", &Tuning::matvec_ksplit},
     {"FPGPU_MATVEC_T", &Tuning::matvec_t},         {"FPGPU_MATMUL_MFMA", &Tuning::matmul_mfma},
     {"FPGPU_MATMUL_GENERIC", &Tuning::matmul_generic}, {"FPGPU_SPMV_LOG2G", &Tuning::spmv_log2g},
+    {"FPGPU_ALLGATHER_COPY", &Tuning::allgather_copy},
 };
 static Tuning g_tuning_defaults;
 static Tuning g_tuning;
@@ -175,26 +173,6 @@ int check_ptr(const fpgpu_ctx* ctx, const void* p, const char* name) {
     if ((uintptr_t)p % align) return fail(FPGPU_ERR_SHAPE, std::string("misaligned device pointer: ") + name);
     return FPGPU_OK;
 }
-#define CHECK(expr)                 \
-    do {                            \
-        int _rc = (expr);           \
-        if (_rc != FPGPU_OK) return _rc; \
-    } while (0)
-
-// Dispatch on the compiled limb counts.
-#define DISPATCH_N64(n64, ...)                                                      \
-    switch (n64) {                                                                  \
-        case 1: { constexpr int N = 2; __VA_ARGS__; } break;                               \
-        case 2: { constexpr int N = 4; __VA_ARGS__; } break;                               \
-        case 3: { constexpr int N = 6; __VA_ARGS__; } break;                               \
-        case 4: { constexpr int N = 8; __VA_ARGS__; } break;                               \
-        case 5: { constexpr int N = 10; __VA_ARGS__; } break;                              \
-        case 6: { constexpr int N = 12; __VA_ARGS__; } break;                              \
-        case 7: { constexpr int N = 14; __VA_ARGS__; } break;                              \
-        case 8: { constexpr int N = 16; __VA_ARGS__; } break;                              \
-        default: return fail(FPGPU_ERR_UNSUPPORTED, "unsupported limb count");      \
-    }
-
 template <int OP>
 int elementwise_dev(const fpgpu_ctx* ctx, const void* a, const void* b, void* out, size_t n, void* stream) {
     CHECK(check_common(ctx, n));
@@ -494,12 +472,32 @@ int fpgpu_product_dev(const fpgpu_ctx* ctx, const void* v, size_t n, void* out, 
     return fold_dev(true, ctx, v, n, out, workspace, workspace_bytes, stream);
 }
 
+int fpgpu_dot_dev(const fpgpu_ctx* ctx, const void* a, const void* b, size_t n, void* out, void* workspace,
+                  size_t workspace_bytes, void* stream) {
+    CHECK(check_common(ctx, n));
+    CHECK(check_ptr(ctx, out, "out"));
+    hipStream_t s = (hipStream_t)stream;
+    if (n == 0) {  // the empty sum is zero (src/semiring.rs:213-226)
+        HIP_TRY(hipMemsetAsync(out, 0, ctx->n64 * 8, s));
+        return FPGPU_OK;
+    }
+    CHECK(check_ptr(ctx, a, "a"));
+    CHECK(check_ptr(ctx, b, "b"));
+    if (n > (size_t)kBlock) {
+        if (!workspace || (uintptr_t)workspace % 16) return fail(FPGPU_ERR_SHAPE, "dot: workspace null or misaligned");
+        if (workspace_bytes < fpgpu_fold_workspace_bytes(ctx)) return fail(FPGPU_ERR_SHAPE, "dot: workspace too small");
+    }
+    DISPATCH_N64(ctx->n64, HIP_TRY(Launch<N>::dot(ctx, a, b, n, out, workspace, s)));
+    HIP_TRY(hipGetLastError());
+    return FPGPU_OK;
+}
+
 int fpgpu_fill_random_dev(const fpgpu_ctx* ctx, void* out, size_t n, uint64_t seed, void* stream) {
     CHECK(check_common(ctx, n));
     if (n == 0) return FPGPU_OK;
     CHECK(check_ptr(ctx, out, "out"));
     hipStream_t s = (hipStream_t)stream;
-    DISPATCH_N64(ctx->n64, HIP_TRY(Launch<N>::fill_random(ctx, out, n, seed, s)));
+    DISPATCH_N64(ctx->n64, HIP_TRY(Launch<N>::fill_random(ctx, out, n, seed, 0, s)));
     HIP_TRY(hipGetLastError());
     return FPGPU_OK;
 }
@@ -565,6 +563,26 @@ static int fold_host(bool product, const fpgpu_ctx* ctx, const uint64_t* v, size
 int fpgpu_sum(const fpgpu_ctx* ctx, const uint64_t* v, size_t n, uint64_t* out) { return fold_host(false, ctx, v, n, out); }
 int fpgpu_product(const fpgpu_ctx* ctx, const uint64_t* v, size_t n, uint64_t* out) {
     return fold_host(true, ctx, v, n, out);
+}
+
+int fpgpu_dot(const fpgpu_ctx* ctx, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out) {
+    CHECK(check_common(ctx, n));
+    if (!out || (n && (!a || !b))) return fail(FPGPU_ERR_SHAPE, "null host pointer");
+    CHECK(require_device());
+    size_t esz = ctx->n64 * 8;
+    DevBuf da, db, dout, ws;
+    CHECK(da.alloc(n * esz));
+    CHECK(db.alloc(n * esz));
+    CHECK(dout.alloc(esz));
+    CHECK(ws.alloc(fpgpu_fold_workspace_bytes(ctx)));
+    if (n) {
+        HIP_TRY(hipMemcpy(da.p, a, n * esz, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(db.p, b, n * esz, hipMemcpyHostToDevice));
+    }
+    CHECK(fpgpu_dot_dev(ctx, da.p, db.p, n, dout.p, ws.p, fpgpu_fold_workspace_bytes(ctx), nullptr));
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    HIP_TRY(hipMemcpy(out, dout.p, esz, hipMemcpyDeviceToHost));
+    return FPGPU_OK;
 }
 
 int fpgpu_batch_inv(const fpgpu_ctx* ctx, const uint64_t* x, uint64_t* out, uint8_t* zero_flags, size_t n) {

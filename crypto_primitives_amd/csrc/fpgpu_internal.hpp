@@ -1,0 +1,42 @@
+// fpgpu_internal.hpp -- what the translation units of the C ABI share: the thread-local error
+// message, status-code helpers and the dispatch over compiled limb counts.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+
+#include "../../include/fpgpu.h"
+#include "fp_launch.hpp"
+
+namespace fpgpu {
+
+extern thread_local std::string g_last_error;
+int fail(int code, const std::string& msg);       // records msg for fpgpu_last_error_string(), returns code
+int hip_fail(hipError_t e, const char* what);     // FPGPU_ERR_HIP with the runtime's message
+
+}  // namespace fpgpu
+
+#define HIP_TRY(expr)                                            \
+    do {                                                         \
+        hipError_t _e = (expr);                                  \
+        if (_e != hipSuccess) return ::fpgpu::hip_fail(_e, #expr); \
+    } while (0)
+#define CHECK(expr)                      \
+    do {                                 \
+        int _rc = (expr);                \
+        if (_rc != FPGPU_OK) return _rc; \
+    } while (0)
+
+// Dispatch on the compiled limb counts.
+#define DISPATCH_N64(n64, ...)                                                      \
+    switch (n64) {                                                                  \
+        case 1: { constexpr int N = 2; __VA_ARGS__; } break;                        \
+        case 2: { constexpr int N = 4; __VA_ARGS__; } break;                        \
+        case 3: { constexpr int N = 6; __VA_ARGS__; } break;                        \
+        case 4: { constexpr int N = 8; __VA_ARGS__; } break;                        \
+        case 5: { constexpr int N = 10; __VA_ARGS__; } break;                       \
+        case 6: { constexpr int N = 12; __VA_ARGS__; } break;                       \
+        case 7: { constexpr int N = 14; __VA_ARGS__; } break;                       \
+        case 8: { constexpr int N = 16; __VA_ARGS__; } break;                       \
+        default: return ::fpgpu::fail(FPGPU_ERR_UNSUPPORTED, "unsupported limb count"); \
+    }

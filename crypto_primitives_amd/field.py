@@ -167,6 +167,71 @@ class MontyField:
         check(self._lib.fpgpu_matmul(self._h, _ptr(A), _ptr(B), _ptr(C), m, k, n))
         return C
 
+    # -- handle API: operands are DeviceVector (crypto_primitives_amd.vec); asynchronous, no host copies --
+    def _v3(self, fn, a, b, out):
+        check(fn(self._h, a._h, b._h, out._h))
+        return out
+
+    def _v2(self, fn, a, out):
+        check(fn(self._h, a._h, out._h))
+        return out
+
+    def mul_vec(self, a, b, out): return self._v3(self._lib.fpgpu_vec_mul, a, b, out)
+    def add_vec(self, a, b, out): return self._v3(self._lib.fpgpu_vec_add, a, b, out)
+    def sub_vec(self, a, b, out): return self._v3(self._lib.fpgpu_vec_sub, a, b, out)
+    def sqr_vec(self, a, out): return self._v2(self._lib.fpgpu_vec_sqr, a, out)
+    def neg_vec(self, a, out): return self._v2(self._lib.fpgpu_vec_neg, a, out)
+    def project_vec(self, a, out): return self._v2(self._lib.fpgpu_vec_to_mont, a, out)
+    def lift_vec(self, a, out): return self._v2(self._lib.fpgpu_vec_from_mont, a, out)
+
+    def mul_chain_vec(self, a, b, out, iters):
+        check(self._lib.fpgpu_vec_mul_chain(self._h, a._h, b._h, out._h, iters))
+        return out
+
+    def pow_vec(self, a, exponent: int, out):
+        nw = max(1, (exponent.bit_length() + 63) // 64)
+        ew = np.array([(exponent >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(nw)], dtype=np.uint64)
+        check(self._lib.fpgpu_vec_pow(self._h, a._h, _ptr(ew), nw, out._h))
+        return out
+
+    def inv_vec(self, x, out, want_flags=True):
+        """Batch FieldConfig::inv on handles.  Returns the host flag array (1 = the reference's None)
+        when want_flags, else None (and the call stays asynchronous)."""
+        if not want_flags:
+            check(self._lib.fpgpu_vec_batch_inv(self._h, x._h, out._h, None, None))
+            return None
+        flags = np.zeros(len(x), dtype=np.uint8)
+        cnt = ctypes.c_size_t()
+        check(self._lib.fpgpu_vec_batch_inv(self._h, x._h, out._h, _ptr(flags), ctypes.byref(cnt)))
+        assert cnt.value == int(flags.sum())
+        return flags
+
+    def _vred(self, fn, *vs):
+        out = np.zeros(self.n64, dtype=np.uint64)
+        check(fn(self._h, *[v._h for v in vs], _ptr(out)))
+        return out
+
+    def sum_vec(self, v): return self._vred(self._lib.fpgpu_vec_sum, v)
+    def product_vec(self, v): return self._vred(self._lib.fpgpu_vec_product, v)
+    def dot_vec(self, a, b): return self._vred(self._lib.fpgpu_vec_dot, a, b)
+
+    def matvec_vec(self, A, rows, cols, x, y):
+        check(self._lib.fpgpu_vec_matvec(self._h, A._h, rows, cols, x._h, y._h))
+        return y
+
+    def matmul_vec(self, A, B, C, m, k, n):
+        check(self._lib.fpgpu_vec_matmul(self._h, A._h, B._h, C._h, m, k, n))
+        return C
+
+    def dot(self, a, b):
+        """sum_i mul(a[i], b[i]) on host arrays (fpgpu_dot)."""
+        a, b = _np(a, self.n64), _np(b, self.n64)
+        if a.shape != b.shape:
+            raise ValueError("operand length mismatch")
+        out = np.zeros(self.n64, dtype=np.uint64)
+        check(self._lib.fpgpu_dot(self._h, _ptr(a) if a.shape[0] else None, _ptr(b) if b.shape[0] else None, a.shape[0], _ptr(out)))
+        return out
+
     # -- device-tensor batch ops (asynchronous on torch's current stream) --------------
     @staticmethod
     def _stream():

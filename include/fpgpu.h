@@ -42,7 +42,8 @@ enum {
     FPGPU_ERR_UNSUPPORTED = 2,     /* limb count without a compiled kernel */
     FPGPU_ERR_SHAPE = 3,           /* null pointer / size / alignment mismatch */
     FPGPU_ERR_HIP = 4,             /* a HIP runtime call failed; see fpgpu_last_error_string() */
-    FPGPU_ERR_NO_DEVICE = 5        /* no gfx950 device visible: there is no CPU fallback */
+    FPGPU_ERR_NO_DEVICE = 5,       /* no gfx950 device visible: there is no CPU fallback */
+    FPGPU_ERR_RCCL = 6             /* librccl could not be loaded or a collective failed */
 };
 
 #define FPGPU_MAX_N64 8 /* largest compiled element width: 512 bits */
@@ -162,6 +163,13 @@ size_t fpgpu_matmul_workspace_bytes(const fpgpu_ctx *ctx, size_t m, size_t k, si
 int fpgpu_matmul_dev(const fpgpu_ctx *ctx, const void *A, const void *B, void *C, size_t m, size_t k,
                      size_t n, void *workspace, size_t workspace_bytes, void *stream);
 
+/* Dot product sum_i mul(a[i], b[i]): SemiringConfig::sum_refs (src/semiring.rs:213-226) over
+ * helpers::mul::monty_mul -- one row of the mat-vec, spread over the whole GPU.
+ * `out` is ONE element (device); n == 0 gives zero.  `workspace`: fpgpu_fold_workspace_bytes(ctx) bytes
+ * of device scratch (needed when n > 256). */
+int fpgpu_dot_dev(const fpgpu_ctx *ctx, const void *a, const void *b, size_t n, void *out, void *workspace,
+                  size_t workspace_bytes, void *stream);
+
 /* ---- synthetic inputs -------------------------------
  * Fills `out` with n uniform elements in [0, p): word l of element i is
  * splitmix64(seed ^ (i*n64 + l)), the value masked to bitlen(p) bits, minus p once if >= p.
@@ -182,6 +190,7 @@ int fpgpu_pow(const fpgpu_ctx *ctx, const uint64_t *a, const uint64_t *exponent_
               uint64_t *out, size_t n);
 int fpgpu_sum(const fpgpu_ctx *ctx, const uint64_t *v, size_t n, uint64_t *out);
 int fpgpu_product(const fpgpu_ctx *ctx, const uint64_t *v, size_t n, uint64_t *out);
+int fpgpu_dot(const fpgpu_ctx *ctx, const uint64_t *a, const uint64_t *b, size_t n, uint64_t *out);
 int fpgpu_batch_inv(const fpgpu_ctx *ctx, const uint64_t *x, uint64_t *out, uint8_t *zero_flags, size_t n);
 int fpgpu_matvec(const fpgpu_ctx *ctx, const uint64_t *A, size_t rows, size_t cols, const uint64_t *x,
                  uint64_t *y);
@@ -190,10 +199,96 @@ int fpgpu_spmv(const fpgpu_ctx *ctx, const uint64_t *vals, const uint32_t *col_i
 int fpgpu_matmul(const fpgpu_ctx *ctx, const uint64_t *A, const uint64_t *B, uint64_t *C, size_t m,
                  size_t k, size_t n);
 
+/* ---- device-resident vectors and multi-GPU sharding -------------------------------------
+ * The reference's containers are host memory -- Vec<T>, DenseRowMatrix<T>::data
+ * (src/matrix.rs:135-145), and one heap allocation per element for BoxedMontyField
+ * (src/field/crypto_bigint_boxed_monty.rs:62-64) -- so a host-buffer call pays PCIe for every
+ * operand.  An fpgpu_vec keeps a vector (or a matrix's row-major data) in HBM between calls: a host
+ * without HIP bindings (the Rust adapter) allocates, uploads, chains any number of operations
+ * with no host copy, and downloads the result.
+ *
+ * Placement: a device index >= 0, or
+ *   FPGPU_PLACE_CURRENT     the calling thread's current HIP device,
+ *   FPGPU_PLACE_SHARDED     contiguous, balanced element ranges over the device list (whole rows
+ *                           per device with fpgpu_vec_alloc_rows: the reference's own parallel axis,
+ *                           rayon over par_chunks_exact(num_cols), src/matrix.rs:170-184),
+ *   FPGPU_PLACE_REPLICATED  one full copy on every device of the list (mat-vec's x, mat-mul's B,
+ *                           gathered results).
+ * The device list is set with fpgpu_set_devices (ids may repeat: every entry gets its own stream
+ * and range, which lets one GPU rehearse a multi-GPU layout); until it is set, "the list" is the
+ * current device alone.  One host thread drives all devices: every list entry owns a stream and all
+ * handle operations are asynchronous on those streams and ordered per device.  Host memory is only
+ * touched by upload / download and by the calls that return a value (sum, product, dot, flags).
+ *
+ * Operands of one call must be laid out alike: same partition as the output, or replicated (a
+ * replica on the output's device serves any range).  Workspaces are the library's (a grow-only
+ * block per list entry).  fpgpu_vec_part exposes each part's device pointer and stream so that
+ * the *_dev entry points and other HIP code can work on the same memory in stream order. */
+typedef struct fpgpu_vec fpgpu_vec;
+#define FPGPU_PLACE_CURRENT (-1)
+#define FPGPU_PLACE_SHARDED (-2)
+#define FPGPU_PLACE_REPLICATED (-3)
+
+/* count == 0 (ids may be NULL) returns to "current device alone".  Existing vectors stay valid. */
+int fpgpu_set_devices(const int *ids, int count);
+int fpgpu_get_devices(int *ids, int capacity); /* returns the list's length (0 = not set) */
+
+int fpgpu_vec_alloc(const fpgpu_ctx *ctx, size_t n, int placement, fpgpu_vec **out);
+/* rows * cols elements; a sharded placement gives every device whole rows */
+int fpgpu_vec_alloc_rows(const fpgpu_ctx *ctx, size_t rows, size_t cols, int placement, fpgpu_vec **out);
+void fpgpu_vec_free(fpgpu_vec *v);
+size_t fpgpu_vec_len(const fpgpu_vec *v);
+int fpgpu_vec_parts(const fpgpu_vec *v);
+/* part i: its device, element range [first, first + count), device pointer and stream (any output may be NULL) */
+int fpgpu_vec_part(const fpgpu_vec *v, int i, int *device, size_t *first, size_t *count, void **dev_ptr,
+                   void **stream);
+/* elements [first, first + n) <- host / -> host; both return when the host buffer is the caller's again.
+ * `host` is n * n64 words in the reference's layout (a &[MontyFieldElement] as it lies). */
+int fpgpu_vec_upload(fpgpu_vec *v, const uint64_t *host, size_t first, size_t n);
+int fpgpu_vec_download(const fpgpu_vec *v, uint64_t *host, size_t first, size_t n);
+int fpgpu_vec_sync(const fpgpu_vec *v); /* wait for everything queued on the vector's devices */
+/* dst <- src between any two layouts of equal length: scatter, gather (sharded -> replicated is an
+ * all-gather by direct peer copies), re-shard, replicate; device to device */
+int fpgpu_vec_copy(fpgpu_vec *dst, const fpgpu_vec *src);
+/* the synthetic generator of fpgpu_fill_random_dev; element i of the VECTOR gets sequence item i whatever the layout */
+int fpgpu_vec_fill_random(const fpgpu_ctx *ctx, fpgpu_vec *v, uint64_t seed);
+
+/* handle forms of the batch operations above (same reference methods, same results) */
+int fpgpu_vec_mul(const fpgpu_ctx *ctx, const fpgpu_vec *a, const fpgpu_vec *b, fpgpu_vec *out);
+int fpgpu_vec_sqr(const fpgpu_ctx *ctx, const fpgpu_vec *a, fpgpu_vec *out);
+int fpgpu_vec_add(const fpgpu_ctx *ctx, const fpgpu_vec *a, const fpgpu_vec *b, fpgpu_vec *out);
+int fpgpu_vec_sub(const fpgpu_ctx *ctx, const fpgpu_vec *a, const fpgpu_vec *b, fpgpu_vec *out);
+int fpgpu_vec_neg(const fpgpu_ctx *ctx, const fpgpu_vec *a, fpgpu_vec *out);
+int fpgpu_vec_to_mont(const fpgpu_ctx *ctx, const fpgpu_vec *a, fpgpu_vec *out);
+int fpgpu_vec_from_mont(const fpgpu_ctx *ctx, const fpgpu_vec *a, fpgpu_vec *out);
+int fpgpu_vec_mul_chain(const fpgpu_ctx *ctx, const fpgpu_vec *a, const fpgpu_vec *b, fpgpu_vec *out, uint32_t iters);
+int fpgpu_vec_pow(const fpgpu_ctx *ctx, const fpgpu_vec *a, const uint64_t *exponent_le, uint32_t exponent_words,
+                  fpgpu_vec *out);
+/* every device inverts its own range with Montgomery's trick: no collective.  none_flags_host (n
+ * bytes, HOST) and none_count may be NULL; asking for either makes the call synchronous. */
+int fpgpu_vec_batch_inv(const fpgpu_ctx *ctx, const fpgpu_vec *x, fpgpu_vec *out, uint8_t *none_flags_host,
+                        size_t *none_count);
+/* one element to HOST memory (synchronous); per-device partials are folded on the first device */
+int fpgpu_vec_sum(const fpgpu_ctx *ctx, const fpgpu_vec *v, uint64_t *out_host);
+int fpgpu_vec_product(const fpgpu_ctx *ctx, const fpgpu_vec *v, uint64_t *out_host);
+int fpgpu_vec_dot(const fpgpu_ctx *ctx, const fpgpu_vec *a, const fpgpu_vec *b, uint64_t *out_host);
+/* y = A x.  A: rows * cols elements with whole rows per part (fpgpu_vec_alloc_rows); x: cols elements,
+ * whole on every device that holds rows (replicated, or on A's device); y: rows elements, either
+ * partitioned like A's rows (no communication) or replicated: then every device's row block is
+ * all-gathered into every copy -- ncclAllGather / ncclBroadcast over xGMI through communicators made
+ * by ncclCommInitAll for the device list (librccl is loaded at the first such call); direct peer
+ * copies instead when the list names a device twice or FPGPU_ALLGATHER_COPY is set. */
+int fpgpu_vec_matvec(const fpgpu_ctx *ctx, const fpgpu_vec *A, size_t rows, size_t cols, const fpgpu_vec *x,
+                     fpgpu_vec *y);
+/* C = A B.  A (m x k) and C (m x n) in row blocks, B (k x n) whole on every device; a replicated C is
+ * all-gathered as above. */
+int fpgpu_vec_matmul(const fpgpu_ctx *ctx, const fpgpu_vec *A, const fpgpu_vec *B, fpgpu_vec *C, size_t m, size_t k,
+                     size_t n);
+
 /* ---- tuning / test hooks -----------------------------------------------------
  * No counterpart in the reference.  The hooks of INTEGRATION.md section 4 (FPGPU_GRID_CAP,
  * FPGPU_INV_C, FPGPU_MATVEC_MFMA, FPGPU_MATVEC_KSPLIT, FPGPU_MATVEC_T, FPGPU_MATMUL_MFMA,
- * FPGPU_MATMUL_GENERIC, FPGPU_SPMV_LOG2G) are read from the environment once, when the library
+ * FPGPU_MATMUL_GENERIC, FPGPU_SPMV_LOG2G, FPGPU_ALLGATHER_COPY) are read from the environment once, when the library
  * is first used; this call sets one afterwards (process-wide; FPGPU_TUNING_DEFAULT restores the
  * library's choice).  No hook changes a result -- they pick between bit-identical paths.  Not
  * synchronised against calls running on other threads. */

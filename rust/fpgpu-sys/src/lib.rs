@@ -12,6 +12,12 @@ pub struct fpgpu_ctx {
     _private: [u8; 0],
 }
 
+/// Opaque `fpgpu_vec`: a device-resident vector (one device, sharded, or replicated over the device list).
+#[repr(C)]
+pub struct fpgpu_vec {
+    _private: [u8; 0],
+}
+
 pub const FPGPU_OK: c_int = 0;
 /// Even or zero modulus: `FieldError::InvalidModulus` (src/field.rs:345-349).
 pub const FPGPU_ERR_INVALID_MODULUS: c_int = 1;
@@ -20,6 +26,11 @@ pub const FPGPU_ERR_SHAPE: c_int = 3;
 pub const FPGPU_ERR_HIP: c_int = 4;
 /// No gfx950 device visible: there is no CPU fallback.
 pub const FPGPU_ERR_NO_DEVICE: c_int = 5;
+/// librccl could not be loaded or a collective failed.
+pub const FPGPU_ERR_RCCL: c_int = 6;
+pub const FPGPU_PLACE_CURRENT: c_int = -1;
+pub const FPGPU_PLACE_SHARDED: c_int = -2;
+pub const FPGPU_PLACE_REPLICATED: c_int = -3;
 pub const FPGPU_MAX_N64: u32 = 8;
 pub const FPGPU_STATIC_SCRATCH_BYTES: usize = 64 << 20;
 pub const FPGPU_TUNING_DEFAULT: c_long = -0x7fff_ffff - 1;
@@ -54,6 +65,9 @@ extern "C" {
                          workspace_bytes: usize, stream: *mut c_void) -> c_int;
     pub fn fpgpu_product_dev(ctx: *const fpgpu_ctx, v: *const c_void, n: usize, out: *mut c_void, workspace: *mut c_void,
                              workspace_bytes: usize, stream: *mut c_void) -> c_int;
+
+    pub fn fpgpu_dot_dev(ctx: *const fpgpu_ctx, a: *const c_void, b: *const c_void, n: usize, out: *mut c_void,
+                         workspace: *mut c_void, workspace_bytes: usize, stream: *mut c_void) -> c_int;
 
     // ---- batch inversion
     pub fn fpgpu_batch_inv_workspace_bytes(ctx: *const fpgpu_ctx, n: usize) -> usize;
@@ -91,11 +105,49 @@ extern "C" {
                      n: usize) -> c_int;
     pub fn fpgpu_sum(ctx: *const fpgpu_ctx, v: *const u64, n: usize, out: *mut u64) -> c_int;
     pub fn fpgpu_product(ctx: *const fpgpu_ctx, v: *const u64, n: usize, out: *mut u64) -> c_int;
+    pub fn fpgpu_dot(ctx: *const fpgpu_ctx, a: *const u64, b: *const u64, n: usize, out: *mut u64) -> c_int;
     pub fn fpgpu_batch_inv(ctx: *const fpgpu_ctx, x: *const u64, out: *mut u64, zero_flags: *mut u8, n: usize) -> c_int;
     pub fn fpgpu_matvec(ctx: *const fpgpu_ctx, a: *const u64, rows: usize, cols: usize, x: *const u64, y: *mut u64) -> c_int;
     pub fn fpgpu_spmv(ctx: *const fpgpu_ctx, vals: *const u64, col_idx: *const u32, rows: usize, cols: usize,
                       density: usize, x: *const u64, y: *mut u64) -> c_int;
     pub fn fpgpu_matmul(ctx: *const fpgpu_ctx, a: *const u64, b: *const u64, c: *mut u64, m: usize, k: usize, n: usize) -> c_int;
+
+    // ---- device-resident vectors and multi-GPU sharding (one host thread drives every device)
+    pub fn fpgpu_set_devices(ids: *const c_int, count: c_int) -> c_int;
+    pub fn fpgpu_get_devices(ids: *mut c_int, capacity: c_int) -> c_int;
+    pub fn fpgpu_vec_alloc(ctx: *const fpgpu_ctx, n: usize, placement: c_int, out: *mut *mut fpgpu_vec) -> c_int;
+    pub fn fpgpu_vec_alloc_rows(ctx: *const fpgpu_ctx, rows: usize, cols: usize, placement: c_int,
+                                out: *mut *mut fpgpu_vec) -> c_int;
+    pub fn fpgpu_vec_free(v: *mut fpgpu_vec);
+    pub fn fpgpu_vec_len(v: *const fpgpu_vec) -> usize;
+    pub fn fpgpu_vec_parts(v: *const fpgpu_vec) -> c_int;
+    pub fn fpgpu_vec_part(v: *const fpgpu_vec, i: c_int, device: *mut c_int, first: *mut usize, count: *mut usize,
+                          dev_ptr: *mut *mut c_void, stream: *mut *mut c_void) -> c_int;
+    pub fn fpgpu_vec_upload(v: *mut fpgpu_vec, host: *const u64, first: usize, n: usize) -> c_int;
+    pub fn fpgpu_vec_download(v: *const fpgpu_vec, host: *mut u64, first: usize, n: usize) -> c_int;
+    pub fn fpgpu_vec_sync(v: *const fpgpu_vec) -> c_int;
+    pub fn fpgpu_vec_copy(dst: *mut fpgpu_vec, src: *const fpgpu_vec) -> c_int;
+    pub fn fpgpu_vec_fill_random(ctx: *const fpgpu_ctx, v: *mut fpgpu_vec, seed: u64) -> c_int;
+    pub fn fpgpu_vec_mul(ctx: *const fpgpu_ctx, a: *const fpgpu_vec, b: *const fpgpu_vec, out: *mut fpgpu_vec) -> c_int;
+    pub fn fpgpu_vec_sqr(ctx: *const fpgpu_ctx, a: *const fpgpu_vec, out: *mut fpgpu_vec) -> c_int;
+    pub fn fpgpu_vec_add(ctx: *const fpgpu_ctx, a: *const fpgpu_vec, b: *const fpgpu_vec, out: *mut fpgpu_vec) -> c_int;
+    pub fn fpgpu_vec_sub(ctx: *const fpgpu_ctx, a: *const fpgpu_vec, b: *const fpgpu_vec, out: *mut fpgpu_vec) -> c_int;
+    pub fn fpgpu_vec_neg(ctx: *const fpgpu_ctx, a: *const fpgpu_vec, out: *mut fpgpu_vec) -> c_int;
+    pub fn fpgpu_vec_to_mont(ctx: *const fpgpu_ctx, a: *const fpgpu_vec, out: *mut fpgpu_vec) -> c_int;
+    pub fn fpgpu_vec_from_mont(ctx: *const fpgpu_ctx, a: *const fpgpu_vec, out: *mut fpgpu_vec) -> c_int;
+    pub fn fpgpu_vec_mul_chain(ctx: *const fpgpu_ctx, a: *const fpgpu_vec, b: *const fpgpu_vec, out: *mut fpgpu_vec,
+                               iters: u32) -> c_int;
+    pub fn fpgpu_vec_pow(ctx: *const fpgpu_ctx, a: *const fpgpu_vec, exponent_le: *const u64, exponent_words: u32,
+                         out: *mut fpgpu_vec) -> c_int;
+    pub fn fpgpu_vec_batch_inv(ctx: *const fpgpu_ctx, x: *const fpgpu_vec, out: *mut fpgpu_vec, none_flags_host: *mut u8,
+                               none_count: *mut usize) -> c_int;
+    pub fn fpgpu_vec_sum(ctx: *const fpgpu_ctx, v: *const fpgpu_vec, out_host: *mut u64) -> c_int;
+    pub fn fpgpu_vec_product(ctx: *const fpgpu_ctx, v: *const fpgpu_vec, out_host: *mut u64) -> c_int;
+    pub fn fpgpu_vec_dot(ctx: *const fpgpu_ctx, a: *const fpgpu_vec, b: *const fpgpu_vec, out_host: *mut u64) -> c_int;
+    pub fn fpgpu_vec_matvec(ctx: *const fpgpu_ctx, a: *const fpgpu_vec, rows: usize, cols: usize, x: *const fpgpu_vec,
+                            y: *mut fpgpu_vec) -> c_int;
+    pub fn fpgpu_vec_matmul(ctx: *const fpgpu_ctx, a: *const fpgpu_vec, b: *const fpgpu_vec, c: *mut fpgpu_vec, m: usize,
+                            k: usize, n: usize) -> c_int;
 
     // ---- tuning / test hooks (process-wide; FPGPU_TUNING_DEFAULT restores the default)
     pub fn fpgpu_tuning_set(name: *const c_char, value: c_long) -> c_int;

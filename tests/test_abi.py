@@ -79,22 +79,48 @@ def test_no_cpu_fallback_without_gpu():
         f.inv(a)
 
 
+_C_TO_RUST = {
+    "int": "c_int", "long": "c_long", "size_t": "usize", "uint32_t": "u32", "uint64_t": "u64", "void": "()",
+    "const char *": "*const c_char", "const int *": "*const c_int", "int *": "*mut c_int", "size_t *": "*mut usize",
+    "const void *": "*const c_void", "void *": "*mut c_void", "void **": "*mut *mut c_void",
+    "const uint64_t *": "*const u64", "uint64_t *": "*mut u64", "const uint32_t *": "*const u32", "uint8_t *": "*mut u8",
+    "const fpgpu_ctx *": "*const fpgpu_ctx", "fpgpu_ctx *": "*mut fpgpu_ctx", "fpgpu_ctx **": "*mut *mut fpgpu_ctx",
+    "const fpgpu_vec *": "*const fpgpu_vec", "fpgpu_vec *": "*mut fpgpu_vec", "fpgpu_vec **": "*mut *mut fpgpu_vec",
+}
+
+
+def _c_param_type(decl):
+    """'const uint64_t *modulus_le' -> 'const uint64_t *' (the declarator's name dropped, spacing normalised)."""
+    decl = " ".join(decl.replace("*", " * ").split())
+    toks = decl.split(" ")
+    if toks[-1] != "*" and len(toks) > 1 and re.fullmatch(r"[A-Za-z_][A-Za-z0-9_]*", toks[-1]) and \
+            toks[-1] not in ("int", "long", "void", "size_t", "uint32_t", "uint64_t", "uint8_t", "char"):
+        toks = toks[:-1]
+    t = " ".join(toks).replace(" * *", " **")
+    return t
+
+
 def test_rust_sys_crate_binds_every_declared_symbol():
-    """rust/fpgpu-sys cannot be compiled in this image (no cargo); at least keep its extern block
-    in step with the header: same set of functions, same argument counts."""
+    """rust/fpgpu-sys cannot be compiled in this image (no cargo); keep its extern block in step with
+    the header: the same set of functions, and for every function the same parameter TYPES in the
+    same order (pointer constness, usize / u32 / u64 / c_int widths) and the same return type."""
     hdr = open(os.path.join(ROOT, "include", "fpgpu.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
     rs = open(os.path.join(ROOT, "rust", "fpgpu-sys", "src", "lib.rs")).read()
     rs = re.sub(r"//.*", "", rs)
-    c_decl = {m.group(1): m.group(2) for m in re.finditer(r"\b(fpgpu_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", hdr)}
-    r_decl = {m.group(1): m.group(2) for m in re.finditer(r"pub fn (fpgpu_[a-z0-9_]+)\s*\(([^)]*)\)", rs)}
+    c_decl = {m.group(2): (m.group(1), m.group(3))
+              for m in re.finditer(r"([A-Za-z_][A-Za-z0-9_ ]*?[ \*]+)(fpgpu_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", hdr)}
+    r_decl = {m.group(1): (m.group(3) or "()", m.group(2))
+              for m in re.finditer(r"pub fn (fpgpu_[a-z0-9_]+)\s*\(([^)]*)\)\s*(?:->\s*([^;]+?))?\s*;", rs)}
     assert sorted(c_decl) == sorted(r_decl)
-
-    def nargs(a):
-        a = a.strip()
-        return 0 if a in ("", "void") else a.count(",") + 1
-    for name in c_decl:
-        assert nargs(c_decl[name]) == nargs(r_decl[name]), name
+    assert len(c_decl) >= 70
+    for name, (cret, cargs) in c_decl.items():
+        rret, rargs = r_decl[name]
+        cargs = cargs.strip()
+        ctypes_ = [] if cargs in ("", "void") else [_c_param_type(a) for a in cargs.split(",")]
+        rtypes = [a.split(":", 1)[1].strip() for a in rargs.split(",") if a.strip()]
+        assert [_C_TO_RUST[t] for t in ctypes_] == rtypes, (name, ctypes_, rtypes)
+        assert _C_TO_RUST[_c_param_type(cret + " x")] == rret.strip(), (name, cret, rret)
 
 
 def test_batch_inv_workspace_plan_is_sane(tuning):

@@ -1,0 +1,278 @@
+"""GPU: the handle API of the C ABI (fpgpu_vec_*, fpgpu_set_devices) against the oracle, bit for bit.
+
+What it pins down:
+  * chains of operations on HBM-resident vectors with no host copy between upload and download;
+  * every layout -- one device, sharded, replicated -- gives the same bits as the unsharded call,
+    ragged partitions included;
+  * the sharded matrix products with a device list of length 1 (RCCL communicator from
+    ncclCommInitAll, ncclAllGather of the output) and with a list that names the GPU three times
+    (three streams, three row blocks, all-gather by peer copies: a single-GPU rehearsal of the N > 1
+    layout -- RCCL itself refuses duplicate devices);
+  * layout mismatches are errors, not silent misreads.
+"""
+import random
+
+import numpy as np
+import pytest
+
+from conftest import h2i, ints_to_array, load_golden, synth_elements
+
+pytestmark = pytest.mark.gpu
+
+LISTS = [None, [0], [0, 0, 0]]
+
+
+@pytest.fixture(scope="module")
+def cpa():
+    import crypto_primitives_amd as c
+    assert c.load().fpgpu_device_count() >= 1, "no MI355X visible"
+    return c
+
+
+@pytest.fixture
+def devices(cpa):
+    def set_(ids):
+        cpa.set_devices(ids or [])
+    yield set_
+    cpa.set_devices([])
+
+
+def _read_device(ptr, n, n64):
+    """n elements at a raw device pointer (a part of a vector), through the process's HIP runtime."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so.7")
+    out = np.empty((n, n64), dtype=np.uint64)
+    if n:
+        rc = hip.hipMemcpy(ctypes.c_void_p(out.ctypes.data), ctypes.c_void_p(ptr), ctypes.c_size_t(n * n64 * 8), 2)
+        assert rc == 0
+    return out
+
+
+def _field(cpa, name):
+    from oracle.fp_oracle import Oracle
+    g = load_golden(name)
+    p, n64 = h2i(g["modulus"]), g["n64"]
+    return cpa.MontyField(p, n64), Oracle(p, n64), p, n64
+
+
+@pytest.mark.parametrize("ids", LISTS, ids=["unset", "list1", "list3same"])
+@pytest.mark.parametrize("name,n", [("bn254_fr", 10007), ("bls12_381_fq", 4099), ("goldilocks", 70001), ("bn254_fr", 2)])
+def test_chained_ops_on_handles_no_host_copies(cpa, devices, ids, name, n):
+    """upload a, b once; t = a*b; u = t + a; v = u^2; w = inv(v); s = w - b; r = -s; download r.
+    Six dependent operations, every intermediate stays in HBM; sharded vectors use contiguous
+    balanced ranges (n = 2 over three entries leaves one of them empty)."""
+    devices(ids)
+    f, o, p, n64 = _field(cpa, name)
+    V = cpa.DeviceVector
+    place = cpa.PLACE_CURRENT if ids is None else cpa.PLACE_SHARDED
+    xs = synth_elements(p, n64, n, 7)
+    ys = synth_elements(p, n64, n, 8)
+    xs[0] = 0                      # a*b + a = 0 -> squares to 0 -> inv gives None there
+    ha, hb = ints_to_array(xs, n64), ints_to_array(ys, n64)
+    a, b = V.from_host(f, ha, place), V.from_host(f, hb, place)
+    t, u, v, w, s, r = (V.alloc(f, n, place) for _ in range(6))
+    f.mul_vec(a, b, t)
+    f.add_vec(t, a, u)
+    f.sqr_vec(u, v)
+    flags = f.inv_vec(v, w)
+    f.sub_vec(w, b, s)
+    f.neg_vec(s, r)
+    got = r.download()
+    ev = o.sqr(o.add(o.mul(ha, hb), ha))
+    ew, eflags = o.batch_inv(ev)
+    assert np.array_equal(flags, eflags) and flags[0] == 1
+    assert np.array_equal(got, o.neg(o.sub(ew, hb)))
+    if ids is not None:
+        assert len(a.parts()) == len(ids)
+        assert sum(c for _, _, c, _, _ in a.parts()) == n
+    # project / lift / pow / mul_chain on the same handles
+    f.project_vec(a, t)
+    f.lift_vec(t, u)
+    assert np.array_equal(u.download(), ha)
+    f.pow_vec(a, 65537, t)
+    assert np.array_equal(t.download(), o.pow(ha, 65537, exponent_bits=64 * n64))
+    f.mul_chain_vec(a, b, t, 5)
+    want = ha.copy()
+    for _ in range(5):
+        want = o.mul(want, hb)
+    assert np.array_equal(t.download(), want)
+
+
+@pytest.mark.parametrize("ids", LISTS, ids=["unset", "list1", "list3same"])
+def test_folds_and_dot_on_handles(cpa, devices, ids):
+    devices(ids)
+    for name, n in (("bn254_fr", 70001), ("bls12_381_fq", 1000), ("goldilocks", 5), ("bn254_fr", 0)):
+        f, o, p, n64 = _field(cpa, name)
+        place = cpa.PLACE_CURRENT if ids is None else cpa.PLACE_SHARDED
+        ha = ints_to_array(synth_elements(p, n64, n, 17), n64)
+        hb = ints_to_array(synth_elements(p, n64, n, 18), n64)
+        a, b = cpa.DeviceVector.from_host(f, ha, place), cpa.DeviceVector.from_host(f, hb, place)
+        assert np.array_equal(f.sum_vec(a), o.sum(ha)), (name, n)
+        assert np.array_equal(f.product_vec(a), o.product(ha)), (name, n)
+        want = o.sum(o.mul(ha, hb)) if n else np.zeros(n64, dtype=np.uint64)
+        assert np.array_equal(f.dot_vec(a, b), want), (name, n)
+        assert np.array_equal(f.dot(ha, hb), want), (name, n)          # host-buffer entry point
+        if ids is not None:
+            # a replicated operand lines up with any partition
+            rb = cpa.DeviceVector.from_host(f, hb, cpa.PLACE_REPLICATED)
+            assert np.array_equal(f.dot_vec(a, rb), want)
+
+
+def test_dot_dev_edge_values_and_lengths(cpa):
+    """fpgpu_dot_dev == the oracle's fold of mul then add at lengths around the wave / workgroup /
+    partial-count boundaries, with operands at the top of the field."""
+    import torch
+    rnd = random.Random(3)
+    for name in ("bn254_fr", "bls12_381_fq", "goldilocks", "secp256k1_p"):
+        f, o, p, n64 = _field(cpa, name)
+        for n in (1, 63, 64, 65, 256, 257, 2049, 600001):
+            xs = [rnd.choice((p - 1, p - 2, rnd.randrange(p))) for _ in range(min(n, 4096))]
+            xs = (xs * (n // len(xs) + 1))[:n]
+            ha, hb = ints_to_array(xs, n64), ints_to_array(xs[::-1], n64)
+            da = torch.from_numpy(ha.view(np.int64)).cuda()
+            db = torch.from_numpy(hb.view(np.int64)).cuda()
+            out = f.alloc(1)
+            ws = torch.empty(f._lib.fpgpu_fold_workspace_bytes(f._h), dtype=torch.uint8, device="cuda")
+            import ctypes
+            from crypto_primitives_amd._lib import check
+            check(f._lib.fpgpu_dot_dev(f._h, f._chk_t(da), f._chk_t(db), n, f._chk_t(out), ctypes.c_void_p(ws.data_ptr()),
+                                       ws.numel(), f._stream()))
+            torch.cuda.synchronize()
+            assert np.array_equal(out.cpu().numpy().view(np.uint64)[0], o.sum(o.mul(ha, hb))), (name, n)
+
+
+@pytest.mark.parametrize("ids", [[0], [0, 0, 0]], ids=["list1_rccl", "list3same_copy"])
+@pytest.mark.parametrize("shape", [(7, 40), (1, 5), (130, 257), (384, 512), (5, 0)])
+def test_sharded_matvec_allgather(cpa, devices, ids, shape):
+    """Row-sharded A, replicated x; y replicated (all-gather of the row blocks: RCCL for the length-1
+    list, peer copies for the list that names the GPU three times) and y sharded (no collective).
+    Ragged row counts (7 over 3, 1 over 3: two devices hold no row)."""
+    devices(ids)
+    rows, cols = shape
+    V = cpa.DeviceVector
+    for name in ("bn254_fr", "goldilocks", "bls12_381_fq"):
+        f, o, p, n64 = _field(cpa, name)
+        hA = ints_to_array(synth_elements(p, n64, rows * cols, 51), n64)
+        hx = ints_to_array(synth_elements(p, n64, cols, 52), n64)
+        want = o.matvec(hA, rows, cols, hx, threads=0)
+        A = V.alloc_rows(f, rows, cols, cpa.PLACE_SHARDED).upload(hA)
+        for _, first, count, _, _ in A.parts():
+            assert cols == 0 or (first % cols == 0 and count % cols == 0)
+        x = V.from_host(f, hx, cpa.PLACE_REPLICATED)
+        y_rep = V.alloc(f, rows, cpa.PLACE_REPLICATED)
+        y_rep.upload(np.full((rows, n64), 0xFF, dtype=np.uint64))
+        f.matvec_vec(A, rows, cols, x, y_rep)
+        assert np.array_equal(y_rep.download(), want), (name, "replicated y")
+        # every copy holds the whole result
+        y_rep.sync()
+        for dev, first, count, ptr, stream in y_rep.parts():
+            assert (first, count) == (0, rows)
+            assert np.array_equal(_read_device(ptr, rows, n64), want), (name, "copy on device", dev)
+        y_sh = V.alloc_rows(f, rows, 1, cpa.PLACE_SHARDED)
+        f.matvec_vec(A, rows, cols, x, y_sh)
+        assert np.array_equal(y_sh.download(), want), (name, "sharded y")
+
+
+@pytest.mark.parametrize("ids", [[0], [0, 0, 0]], ids=["list1_rccl", "list3same_copy"])
+def test_sharded_matmul_allgather(cpa, devices, ids):
+    devices(ids)
+    V = cpa.DeviceVector
+    for name, (m, k, n) in (("goldilocks", (70, 130, 66)), ("goldilocks", (2, 64, 3)), ("bn254_fr", (20, 33, 7))):
+        f, o, p, n64 = _field(cpa, name)
+        hA = ints_to_array(synth_elements(p, n64, m * k, 61), n64)
+        hB = ints_to_array(synth_elements(p, n64, k * n, 62), n64)
+        want = o.matmul(hA, hB, m, k, n, threads=0)
+        A = V.alloc_rows(f, m, k, cpa.PLACE_SHARDED).upload(hA)
+        B = V.from_host(f, hB, cpa.PLACE_REPLICATED)
+        C_sh = V.alloc_rows(f, m, n, cpa.PLACE_SHARDED)
+        f.matmul_vec(A, B, C_sh, m, k, n)
+        assert np.array_equal(C_sh.download().reshape(want.shape), want), (name, "sharded C")
+        C_rep = V.alloc(f, m * n, cpa.PLACE_REPLICATED)
+        f.matmul_vec(A, B, C_rep, m, k, n)
+        assert np.array_equal(C_rep.download().reshape(want.shape), want), (name, "replicated C")
+        # (A B) v == A (B v) with everything on handles: the gathered C feeds the next product
+        hv = ints_to_array(synth_elements(p, n64, n, 63), n64)
+        v = V.from_host(f, hv, cpa.PLACE_REPLICATED)
+        C_rows = V.alloc_rows(f, m, n, cpa.PLACE_SHARDED).copy_from(C_rep)
+        y1 = V.alloc(f, m, cpa.PLACE_REPLICATED)
+        f.matvec_vec(C_rows, m, n, v, y1)
+        Bv = V.alloc(f, k, cpa.PLACE_REPLICATED)
+        Brows = V.alloc_rows(f, k, n, cpa.PLACE_SHARDED).copy_from(B)
+        f.matvec_vec(Brows, k, n, v, Bv)
+        y2 = V.alloc(f, m, cpa.PLACE_REPLICATED)
+        f.matvec_vec(A, m, k, Bv, y2)
+        assert np.array_equal(y1.download(), y2.download())
+        assert np.array_equal(y1.download(), o.matvec(want.reshape(-1, n64), m, n, hv, threads=0))
+
+
+def test_rccl_and_copy_transports_agree_on_a_list_of_one(cpa, devices, tuning):
+    devices([0])
+    f, o, p, n64 = _field(cpa, "bn254_fr")
+    rows, cols = 300, 64
+    V = cpa.DeviceVector
+    hA = ints_to_array(synth_elements(p, n64, rows * cols, 71), n64)
+    hx = ints_to_array(synth_elements(p, n64, cols, 72), n64)
+    A = V.alloc_rows(f, rows, cols, cpa.PLACE_SHARDED).upload(hA)
+    x = V.from_host(f, hx, cpa.PLACE_REPLICATED)
+    y = V.alloc(f, rows, cpa.PLACE_REPLICATED)
+    f.matvec_vec(A, rows, cols, x, y)
+    a = y.download()
+    tuning("FPGPU_ALLGATHER_COPY", 1)
+    f.matvec_vec(A, rows, cols, x, y)
+    assert np.array_equal(a, y.download())
+    assert np.array_equal(a, o.matvec(hA, rows, cols, hx, threads=0))
+
+
+@pytest.mark.parametrize("ids", [[0], [0, 0, 0]], ids=["list1", "list3same"])
+def test_layout_independent_generator_and_redistribution(cpa, devices, ids):
+    """fpgpu_vec_fill_random: element i of the vector is item i of the sequence whatever the layout;
+    fpgpu_vec_copy moves between layouts (scatter, gather, re-shard with other row lengths)."""
+    devices(ids)
+    f, o, p, n64 = _field(cpa, "bls12_381_fq")
+    n = 1000
+    want = ints_to_array(synth_elements(p, n64, n, 0xABC), n64)
+    V = cpa.DeviceVector
+    single = V.alloc(f, n, 0).fill_random(0xABC)
+    sh = V.alloc(f, n, cpa.PLACE_SHARDED).fill_random(0xABC)
+    rep = V.alloc(f, n, cpa.PLACE_REPLICATED).fill_random(0xABC)
+    for v in (single, sh, rep):
+        assert np.array_equal(v.download(), want)
+    assert np.array_equal(sh.download(first=333, n=500), want[333:833])
+    rows = V.alloc_rows(f, 8, 125, cpa.PLACE_SHARDED).copy_from(sh)       # other part boundaries
+    assert np.array_equal(rows.download(), want)
+    back = V.alloc(f, n, cpa.PLACE_REPLICATED).copy_from(rows)           # gather: sharded -> every copy
+    assert np.array_equal(back.download(), want)
+    one = V.alloc(f, n, cpa.PLACE_CURRENT).copy_from(back)
+    assert np.array_equal(one.download(), want)
+    # partial upload into a sharded vector lands in the right parts
+    sh.upload(np.zeros((10, n64), dtype=np.uint64), first=330)
+    want2 = want.copy()
+    want2[330:340] = 0
+    assert np.array_equal(sh.download(), want2)
+
+
+def test_layout_mismatches_are_errors(cpa, devices):
+    devices([0, 0])
+    f, o, p, n64 = _field(cpa, "bn254_fr")
+    V = cpa.DeviceVector
+    a = V.alloc(f, 100, cpa.PLACE_SHARDED)
+    b = V.alloc(f, 100, 0)
+    c = V.alloc(f, 101, cpa.PLACE_SHARDED)
+    with pytest.raises(cpa.FpgpuError, match="partitioned differently"):
+        f.mul_vec(a, b, a)
+    with pytest.raises(cpa.FpgpuError, match="length mismatch"):
+        f.add_vec(a, c, a)
+    g = cpa.MontyField(cpa.GOLDILOCKS, 1)
+    with pytest.raises(cpa.FpgpuError, match="element width"):
+        g.neg_vec(a, a)
+    with pytest.raises(cpa.FpgpuError, match="alias"):
+        f.inv_vec(a, a)
+    A = V.alloc(f, 6 * 5, cpa.PLACE_SHARDED)          # 15 elements per entry: not whole rows of 6... of 5 yes, of 6 no
+    x = V.alloc(f, 6, cpa.PLACE_REPLICATED)
+    y = V.alloc(f, 5, cpa.PLACE_REPLICATED)
+    with pytest.raises(cpa.FpgpuError, match="whole rows"):
+        f.matvec_vec(A, 5, 6, x, y)
+    with pytest.raises(cpa.FpgpuError, match="beyond the vector"):
+        a.download(first=50, n=51)
+    with pytest.raises(cpa.FpgpuError, match="no such device"):
+        V.alloc(f, 4, 99)
