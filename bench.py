@@ -32,7 +32,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-MFMA_I8_PEAK_TOPS = 5000.0      # MI355X_MICROARCH.md: dense int8 MFMA = 2x the ~2.5 PF bf16 peak
+MFMA_I8_PEAK_TOPS = 5000.0      # INFERRED, not a guide figure: 2x the ~2.5 PFLOP/s dense bf16 peak of MI355X_MICROARCH.md
+MFMA_I8_PEAK_NOTE = ("int8 peak is inferred as 2x the guide's ~2.5 PFLOP/s dense bf16 figure (the guide lists no int8 "
+                     "number); measured bare v_mfma_i32_16x16x64_i8 loop: 8.4 ns per MFMA per SIMD = 3.99 POP/s")
 VALU_MAD_PEAK_TOPS = 39.3       # 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz v_mad_u64_u32 lane-ops/s (measured 36.5)
 
 
@@ -46,6 +48,10 @@ def parse():
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary measurements")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--matvec-log2", type=int, default=15, help="mat-vec is 2^k x 2^k")
+    ap.add_argument("--matmul-dim", type=int, default=8192, help="mat-mul is dim^3 (rehearsals only; the config is 8192)")
+    ap.add_argument("--inv-log2", type=int, default=24, help="batch inversion over 2^k elements in total")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="take the multi-rank code path (RCCL process group, all-gather, max over ranks) even at world size 1")
     return ap.parse_args()
 
 
@@ -66,8 +72,13 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
     torch.cuda.set_device(local_rank)
-    distributed = world > 1
+    # under torch.distributed.run the RCCL path is taken even for one rank, so that a one-GPU box can
+    # rehearse exactly the code the N > 1 runs execute (process group, all-gather, max over ranks)
+    distributed = world > 1 or args.force_dist or (world == 1 and "TORCHELASTIC_RUN_ID" in os.environ)
     if distributed:
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
@@ -115,6 +126,7 @@ def main():
 
     result = {}
     extra = {}
+    samples = {}   # small host copies of GPU results; checked against the oracle in the CPU leg only
 
     # ---------------- primary workload ------------------------------------------------
     if args.workload in ops:
@@ -134,14 +146,7 @@ def main():
         achieved = bytes_per * n / kern / 1e9
         # HBM bytes per launch from the PMC passes kept under profiles/ (collected with
         # rocprofv3 --pmc on this same command; bench.py cannot run the profiler on itself)
-        traffic = None
-        try:
-            with open(_latest_profile("pmc_traffic_%s.json" % args.workload)) as fh:
-                pmc = json.load(fh)
-            if pmc.get("elements") == n:
-                traffic = pmc["traffic_bytes_per_launch"]
-        except (OSError, ValueError, KeyError):
-            pass
+        traffic, traffic_src = _pmc_traffic(args.workload, "elements", n)
         result = {
             "metric": "256-bit Montgomery %s (BN254 Fr, HBM-resident batch)" % unit,
             "value": value, "unit": unit,
@@ -152,18 +157,19 @@ def main():
                        "elements_per_gpu": n, "limbs64": 4, "parallelism": "shard%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "traffic_unit": "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r*_pmc_traffic_*.json)",
+                         "traffic_unit": "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE; a stored rocprofv3 pass, bench.py cannot profile itself)",
+                         "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": bytes_per * n,
                          "kernel": "k_elementwise<8,%s>" % args.workload, "bytes_per_element": bytes_per,
                          "kernel_ms": kern * 1e3},
             "verified_vs_oracle": verified,
         }
     elif args.workload == "matvec":
-        result = bench_matvec(args, f, world, rank, distributed, time_steps, primary=True)
+        result = bench_matvec(args, f, world, rank, distributed, time_steps, True, samples)
     elif args.workload == "batch_inv":
-        result = bench_batch_inv(args, world, rank, time_steps, primary=True)
+        result = bench_batch_inv(args, world, rank, time_steps, True, samples)
     elif args.workload == "matmul":
-        result = bench_matmul(args, world, rank, distributed, time_steps, primary=True)
+        result = bench_matmul(args, world, rank, distributed, time_steps, True, samples)
 
     # ---------------- secondary measurements ------------------------------------------
     if not args.no_extra:
@@ -197,19 +203,25 @@ def main():
                               "valu_frac_vs_136_mads": gmul * 136 / 1e3 / VALU_MAD_PEAK_TOPS,
                               "valu_frac_vs_171_executed_mads": gmul * 171 / 1e3 / VALU_MAD_PEAK_TOPS}
         if args.workload != "batch_inv":
-            extra["batch_inv_bls12_381"] = bench_batch_inv(args, world, rank, time_steps, primary=False)
+            extra["batch_inv_bls12_381"] = bench_batch_inv(args, world, rank, time_steps, False, samples)
         if args.workload != "matmul":
-            extra["matmul_goldilocks"] = bench_matmul(args, world, rank, distributed, time_steps, primary=False)
+            extra["matmul_goldilocks"] = bench_matmul(args, world, rank, distributed, time_steps, False, samples)
         if args.workload != "matvec":
-            extra["matvec_bn254"] = bench_matvec(args, f, world, rank, distributed, time_steps, primary=False)
+            extra["matvec_bn254"] = bench_matvec(args, f, world, rank, distributed, time_steps, False, samples)
         extra["spmv_bn254"] = bench_spmv(f, rank, time_steps)
 
     # ---------------- CPU baseline (rank 0, N = 1 only) --------------------------------
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu:
-        cpu = cpu_baseline(sample if args.workload in ops else None)
+        cpu = cpu_baseline(sample if args.workload in ops else None, samples)
         if cpu.get("sample_matches_gpu") is not None:
             result["verified_vs_oracle"] = cpu["sample_matches_gpu"]
+        checks = cpu.get("samples_match_gpu", {})
+        if args.workload in checks:
+            result["verified_vs_oracle"] = checks[args.workload]
+        for key, name in (("batch_inv_bls12_381", "batch_inv"), ("matmul_goldilocks", "matmul"), ("matvec_bn254", "matvec")):
+            if key in extra and name in checks:
+                extra[key]["verified_vs_oracle"] = checks[name]
 
     if rank == 0:
         line = {
@@ -227,21 +239,25 @@ def main():
             "data": "synthetic uniform field elements generated on device (SplitMix64 counter RNG)",
             "config": result.get("config"), "per_gpu": result.get("per_gpu"),
             "roofline": result.get("roofline"), "cpu_baseline": cpu,
-            "verified_vs_oracle": result.get("verified_vs_oracle"), "extra": extra,
+            "verified_vs_oracle": result.get("verified_vs_oracle"),
+            "distributed": {"process_group": "nccl (RCCL)" if distributed else None, "world": world,
+                            "timing": "max over ranks via all_reduce(MAX)" if distributed else "single rank"},
+            "extra": extra,
         }
         print(json.dumps(line), flush=True)
     if distributed:
         dist.destroy_process_group()
 
 
-def bench_batch_inv(args, world, rank, time_steps, primary):
+def bench_batch_inv(args, world, rank, time_steps, primary, samples):
     """BASELINE.json configs[2]: BLS12-381 Fq (384-bit precision) batch inversion over 2^24
     elements, sharded: each rank inverts its own 2^24/world slice (strong scaling)."""
     import torch
     import crypto_primitives_amd as cpa
     fq = cpa.MontyField(cpa.BLS12_381_FQ, 6)
-    total = 1 << 24
+    total = 1 << args.inv_log2
     n = total // world
+    import numpy as np
     x = fq.random_dev(n, 0xB15 ^ (7 + 1000 * rank))
     out = fq.alloc(n)
     flags = torch.empty(n, dtype=torch.uint8, device="cuda")
@@ -251,24 +267,36 @@ def bench_batch_inv(args, world, rank, time_steps, primary):
     # property check: x * inv(x) == one wherever x != 0
     chk = fq.alloc(n)
     fq.mul_dev(x, out, chk)
-    import numpy as np
     one = torch.from_numpy(fq.one_words.view(np.int64)).cuda()
     ok = bool(torch.equal(chk[flags == 0], one.expand(int((flags == 0).sum()), 6)))
+    if rank == 0:
+        idx = torch.arange(0, n, max(1, n // 512), device="cuda")
+        samples["batch_inv"] = (x[idx].cpu().numpy().view(np.uint64), out[idx].cpu().numpy().view(np.uint64))
+    # 3 Montgomery multiplications per element = 3 x (2*12^2 + 12) = 900 32-bit multiplies
+    # (the kernels execute 3.03 x 406 on 14 unsaturated 29-bit limbs)
+    mads = 900.0 * n / kern / 1e12
     res = {"Ginv_per_s": total * steps / wall / 1e9, "ms_per_batch": wall / steps * 1e3,
-           "elements_total": total, "algorithmic_GBps_per_gpu": 96 * n / kern / 1e9,
+           "elements_total": total, "bound": "valu", "mads_per_element": 900,
+           "valu_mad_Tops_per_gpu": mads, "valu_frac": mads / VALU_MAD_PEAK_TOPS,
+           "algorithmic_GBps_per_gpu": 96 * n / kern / 1e9, "hbm_frac": 96 * n / kern / 1e9 / HBM_PEAK_GBPS,
            "x_times_inv_is_one": ok}
     if primary:
+        traffic, traffic_src = _pmc_traffic("batch_inv", "elements", n)
         res = {"metric": "BLS12-381 Fq batch inversion Ginv/s", "value": res["Ginv_per_s"], "unit": "Ginv/s",
                "per_gpu": res["Ginv_per_s"] / world, "ms_per_step": res["ms_per_batch"],
-               "config": {"workload": "BLS12-381 Fq 384-bit batch inversion over 2^24 elements "
-                                      "(BASELINE.json configs[2])", "parallelism": "shard%d" % world},
-               "roofline": {"bound": "hbm", "achieved": 96 * n / kern / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                            "frac": 96 * n / kern / 1e9 / HBM_PEAK_GBPS, "traffic": None},
+               "config": {"workload": "BLS12-381 Fq 384-bit batch inversion over 2^%d elements "
+                                      "(BASELINE.json configs[2])" % args.inv_log2, "parallelism": "shard%d" % world},
+               "roofline": {"bound": "valu", "achieved": mads, "peak": VALU_MAD_PEAK_TOPS,
+                            "unit": "T 32-bit multiply-adds/s (900 per element: 3 Montgomery multiplications of 2*12^2+12)",
+                            "frac": mads / VALU_MAD_PEAK_TOPS, "traffic": traffic, "traffic_source": traffic_src,
+                            "traffic_unit": "HBM bytes per batch, all k_binv_* launches (PMC)",
+                            "algorithmic_bytes_per_launch": 96 * n, "hbm_frac_of_8TBps": res["hbm_frac"],
+                            "kernel": "k_binv_up / k_binv_top / k_binv_down <12>", "kernel_ms": kern * 1e3},
                "verified_vs_oracle": ok}
     return res
 
 
-def bench_matmul(args, world, rank, distributed, time_steps, primary):
+def bench_matmul(args, world, rank, distributed, time_steps, primary, samples):
     """BASELINE.json configs[4]: MontyField 64-bit single-limb prime (Goldilocks) 8192^2 mat-mul.
     A and C are row-sharded across ranks, B is replicated (strong scaling).  The product stays
     row-sharded, as BASELINE.json's north_star has it (an all-gather only reassembles mat-vec outputs);
@@ -276,8 +304,10 @@ def bench_matmul(args, world, rank, distributed, time_steps, primary):
     import torch
     import torch.distributed as dist
     import crypto_primitives_amd as cpa
+    import numpy as np
+    from crypto_primitives_amd import _lib
     g = cpa.MontyField(cpa.GOLDILOCKS, 1)
-    dim = 8192
+    dim = args.matmul_dim
     rows = dim // world
     A = g.random_dev(rows * dim, 0x60 ^ (13 + 1000 * rank))
     B = g.random_dev(dim * dim, 0x61)
@@ -295,10 +325,22 @@ def bench_matmul(args, world, rank, distributed, time_steps, primary):
 
     steps = max(2, min(args.steps, 5)) if not primary else args.steps
     wall, kern = time_steps(step, steps, 1)
+    if rank == 0:   # three rows of C with their rows of A, and B, for the oracle in the CPU leg
+        torch.cuda.synchronize()
+        rs = [0, rows // 2 + 1, rows - 1]
+        samples["matmul"] = (np.stack([A[r * dim:(r + 1) * dim].cpu().numpy().view(np.uint64).reshape(-1) for r in rs]),
+                             B.cpu().numpy().view(np.uint64).reshape(-1),
+                             np.stack([C_local[r * dim:(r + 1) * dim].cpu().numpy().view(np.uint64).reshape(-1) for r in rs]), dim)
     gathered_ms = None
     if distributed:
         wall_g, _ = time_steps(step_gathered, max(2, min(steps, 5)), 1)
         gathered_ms = wall_g / max(2, min(steps, 5)) * 1e3
+    # the VALU kernel on the same product, timed live (tuning hook; same results)
+    _lib.tuning_set("FPGPU_MATMUL_MFMA", 0)
+    try:
+        _, kern_valu = time_steps(step, 2, 1)
+    finally:
+        _lib.tuning_set("FPGPU_MATMUL_MFMA")
     terms = dim ** 3
     # int8 multiply-accumulates the matrix cores execute: 64 digit products per 64x64-bit term
     tops = 2.0 * 64.0 * rows * dim * dim / kern / 1e12
@@ -306,32 +348,28 @@ def bench_matmul(args, world, rank, distributed, time_steps, primary):
            "int8_mfma_Tops_per_gpu": tops, "int8_mfma_peak_Tops": MFMA_I8_PEAK_TOPS,
            "mfma_frac": tops / MFMA_I8_PEAK_TOPS,
            "kernels": "k_mf_digitize x2 + k_matmul_mfma_1limb (v_mfma_i32_16x16x64_i8)",
+           "int8_peak_note": MFMA_I8_PEAK_NOTE,
            "ms_per_matmul_with_allgather_of_C": gathered_ms,
-           "valu_kernel_ms_for_comparison": 125.8}
+           "valu_kernel_ms_same_run": kern_valu * 1e3}
     if primary:
         extra_fields = {"ms_per_step_with_allgather_of_C": gathered_ms}
-        traffic = None   # HBM bytes per launch of the main kernel from the PMC passes under profiles/ (N = 1 shape)
-        try:
-            with open(_latest_profile("pmc_matmul.json")) as fh:
-                pmc = json.load(fh)
-            if pmc.get("dim") == dim and world == 1:
-                traffic = pmc["traffic_bytes_per_launch"]
-        except (OSError, ValueError, KeyError):
-            pass
+        # HBM bytes per launch of the main kernel from the stored PMC passes (N = 1 shape)
+        traffic, traffic_src = _pmc_traffic("matmul", "dim", dim) if world == 1 else (None, "not collected for sharded shapes")
         res = {"metric": "64-bit Fp mat-mul Gterms/s (Goldilocks, 8192^2)", "value": res["Gterms_per_s"],
                "unit": "Gterms/s", "per_gpu": res["Gterms_per_s"] / world, "ms_per_step": res["ms_per_matmul"],
-               "config": {"workload": "Goldilocks 64-bit 8192 x 8192 x 8192 mat-mul (BASELINE.json configs[4])",
+               "config": {"workload": "Goldilocks 64-bit %d x %d x %d mat-mul (BASELINE.json configs[4])" % (dim, dim, dim),
                           "parallelism": "rowshard%d (C stays row-sharded)" % world, **extra_fields},
                "roofline": {"bound": "mfma", "achieved": tops, "peak": MFMA_I8_PEAK_TOPS,
                             "unit": "TOP/s (int8 multiply-accumulates x 2; 64 per 64x64-bit term)",
-                            "frac": tops / MFMA_I8_PEAK_TOPS, "traffic": traffic,
-                            "traffic_unit": "HBM bytes per launch of k_matmul_mfma_1limb (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r*_pmc_matmul.json)",
+                            "frac": tops / MFMA_I8_PEAK_TOPS, "peak_note": MFMA_I8_PEAK_NOTE, "traffic": traffic,
+                            "traffic_source": traffic_src,
+                            "traffic_unit": "HBM bytes per launch of k_matmul_mfma_1limb (PMC FETCH_SIZE x2 + WRITE_SIZE)",
                             "kernel": "k_matmul_mfma_1limb"},
                "verified_vs_oracle": None}
     return res
 
 
-def bench_matvec(args, f, world, rank, distributed, time_steps, primary):
+def bench_matvec(args, f, world, rank, distributed, time_steps, primary, samples):
     """BASELINE.json configs[3]: 256-bit Fp dense mat-vec, rows sharded across ranks,
     y reassembled with an RCCL all-gather (the only collective on the path)."""
     import torch
@@ -352,6 +390,12 @@ def bench_matvec(args, f, world, rank, distributed, time_steps, primary):
 
     steps = args.steps if primary else 5
     wall, kern = time_steps(step, steps, 1)
+    if rank == 0:   # three rows of A, x and their outputs for the oracle in the CPU leg
+        import numpy as np
+        torch.cuda.synchronize()
+        rs = [0, rows // 2 + 1, rows - 1]
+        samples["matvec"] = (np.stack([A[r * dim:(r + 1) * dim].cpu().numpy().view(np.uint64) for r in rs]),
+                             x.cpu().numpy().view(np.uint64), y_local[rs].cpu().numpy().view(np.uint64), dim)
     elems = dim * dim
     res = {"matrix_elems_per_s": elems * steps / wall, "ms_per_matvec": wall / steps * 1e3,
            "dim": dim, "hbm_GBps_per_gpu": 32.0 * (rows * dim + dim + rows) / kern / 1e9,
@@ -364,7 +408,8 @@ def bench_matvec(args, f, world, rank, distributed, time_steps, primary):
                                       "(BASELINE.json configs[3])" % (args.matvec_log2, args.matvec_log2),
                           "parallelism": "rowshard%d+allgather" % world},
                "roofline": {"bound": "hbm", "achieved": res["hbm_GBps_per_gpu"], "peak": HBM_PEAK_GBPS,
-                            "unit": "GB/s", "frac": res["hbm_frac"], "traffic": _pmc_traffic("matvec", "rows", rows),
+                            "unit": "GB/s", "frac": res["hbm_frac"], "traffic": _pmc_traffic("matvec", "rows", rows)[0],
+                            "traffic_source": _pmc_traffic("matvec", "rows", rows)[1],
                             "kernel": "k_matvec_mfma<8,4> (+ k_mv_expand, k_mv_finish)"},
                "verified_vs_oracle": None}
     return res
@@ -395,17 +440,38 @@ def _latest_profile(name):
     return found[-1] if found else os.path.join(ROOT, "profiles", name)
 
 
+def kernel_sources_sha256():
+    """Digest of every kernel source the library is built from.  A stored PMC pass carries the digest of
+    the sources it measured; bench.py only quotes it while the sources are still those."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for path in sorted(glob.glob(os.path.join(ROOT, "crypto_primitives_amd", "csrc", "*"))):
+        if path.endswith((".cuh", ".hip", ".hpp", ".inc")):
+            h.update(os.path.basename(path).encode())
+            h.update(open(path, "rb").read())
+    return h.hexdigest()
+
+
 def _pmc_traffic(workload, key, value):
-    """HBM bytes per launch from the PMC passes kept under profiles/ (bench.py cannot profile itself)."""
+    """(HBM bytes per launch, provenance) from the PMC passes kept under profiles/ (bench.py cannot run the
+    profiler on itself).  Fails closed: no figure when the stored pass measured another problem size
+    or other kernel sources than the ones in the tree."""
+    path = _latest_profile("pmc_traffic_%s.json" % workload)
     try:
-        with open(_latest_profile("pmc_traffic_%s.json" % workload)) as fh:
+        with open(path) as fh:
             pmc = json.load(fh)
-        return pmc["traffic_bytes_per_launch"] if pmc.get(key) == value else None
-    except (OSError, ValueError, KeyError):
-        return None
+    except (OSError, ValueError):
+        return None, "no stored PMC pass for this workload"
+    name = os.path.relpath(path, ROOT)
+    if pmc.get(key) != value:
+        return None, "%s measured %s = %s, not %s" % (name, key, pmc.get(key), value)
+    if pmc.get("kernel_sources_sha256") != kernel_sources_sha256():
+        return None, "%s is stale: the kernel sources changed after it was collected (commit %s)" % (name, pmc.get("commit"))
+    return pmc.get("traffic_bytes_per_launch"), "%s (collected at commit %s, same kernel sources as this tree)" % (name, pmc.get("commit"))
 
 
-def cpu_baseline(sample=None):
+def cpu_baseline(sample=None, samples=None):
     """The CPU restatement of the reference's path (oracle/, "port"), timed on this box's host
     cores: 2^20-element BN254 Fr batches (BASELINE.json configs[0] shape), repeated for a
     bounded ~10 s, all OpenMP threads the box grants.  This leg is also where the GPU's output
@@ -420,6 +486,21 @@ def cpu_baseline(sample=None):
         exp = {"mul": o.mul, "add": o.add, "sub": o.sub}.get(op)
         exp = exp(sa, sb) if exp else o.sqr(sa)
         matches = bool(np.array_equal(sout, exp))
+    checks = {}
+    for name, smp in (samples or {}).items():
+        if name == "matvec":
+            rowsA, x, y, dim = smp
+            checks[name] = all(np.array_equal(o.matvec(rowsA[i], 1, dim, x, threads=0).reshape(-1), y[i].reshape(-1))
+                               for i in range(len(rowsA)))
+        elif name == "matmul":
+            rowsA, B, rowsC, dim = smp
+            og = Oracle(cpa.GOLDILOCKS, 1)
+            checks[name] = all(np.array_equal(og.matmul(rowsA[i].reshape(-1, 1), B.reshape(-1, 1), 1, dim, dim, threads=0).reshape(-1),
+                                              rowsC[i].reshape(-1)) for i in range(len(rowsA)))
+        elif name == "batch_inv":
+            xs, inv = smp
+            oq = Oracle(cpa.BLS12_381_FQ, 6)
+            checks[name] = bool(np.array_equal(oq.batch_inv(xs)[0], inv))
     n = 1 << 20
     rng = np.random.default_rng(1)
     a = rng.integers(0, 1 << 62, size=(n, 4), dtype=np.uint64)
@@ -459,7 +540,8 @@ def cpu_baseline(sample=None):
             "reference_bench_shape_ns_per_op": ref_shape,
             "sample": "%d passes of a 2^20-element BN254 Fr mul batch (C restatement of monty_mul, "
                       "-O3, OpenMP static chunks); single-thread rate %.4f Gmul/s" % (reps, single),
-            "single_thread_Gmul_per_s": single, "add_Gadd_per_s": add_rate, "sample_matches_gpu": matches}
+            "single_thread_Gmul_per_s": single, "add_Gadd_per_s": add_rate, "sample_matches_gpu": matches,
+            "samples_match_gpu": checks}
 
 
 if __name__ == "__main__":

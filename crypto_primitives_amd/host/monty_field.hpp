@@ -216,6 +216,65 @@ struct SparseMatrix {
     bool is_empty() const { return num_rows == 0 || num_cols == 0; }
 };
 
+// ---- DeviceVec: the batch extension's device-side container -------------------------------
+// The reference keeps vectors in host memory (Vec<T>, DenseRowMatrix<T>::data, one heap block per
+// BoxedMontyFieldElement); a DeviceVec is the same elements living in HBM between batch calls
+// (fpgpu_vec of include/fpgpu.h): upload once, chain operations with no host copy, download once.
+// Placement over the device list of set_devices(): one device, sharded (contiguous ranges / whole
+// rows per device) or replicated.
+enum class Placement : int { Current = FPGPU_PLACE_CURRENT, Sharded = FPGPU_PLACE_SHARDED, Replicated = FPGPU_PLACE_REPLICATED };
+inline void set_devices(const std::vector<int>& ids) { fpgpu_check(fpgpu_set_devices(ids.data(), (int)ids.size())); }
+
+class DeviceVec {
+   public:
+    DeviceVec() = default;
+    DeviceVec(const fpgpu_ctx* ctx, size_t n, Placement where, size_t row_len = 0) {
+        fpgpu_vec* raw = nullptr;
+        if (row_len) fpgpu_check(fpgpu_vec_alloc_rows(ctx, n / row_len, row_len, (int)where, &raw));
+        else fpgpu_check(fpgpu_vec_alloc(ctx, n, (int)where, &raw));
+        h_.reset(raw, [](fpgpu_vec* v) { fpgpu_vec_free(v); });
+    }
+    size_t size() const { return h_ ? fpgpu_vec_len(h_.get()) : 0; }
+    int parts() const { return h_ ? fpgpu_vec_parts(h_.get()) : 0; }
+    fpgpu_vec* raw() const { return h_.get(); }
+    void upload(const uint64_t* words, size_t first, size_t n) { fpgpu_check(fpgpu_vec_upload(h_.get(), words, first, n)); }
+    void download(uint64_t* words, size_t first, size_t n) const { fpgpu_check(fpgpu_vec_download(h_.get(), words, first, n)); }
+    void sync() const { fpgpu_check(fpgpu_vec_sync(h_.get())); }
+    void copy_from(const DeviceVec& src) { fpgpu_check(fpgpu_vec_copy(h_.get(), src.raw())); }
+
+   private:
+    std::shared_ptr<fpgpu_vec> h_;
+};
+
+namespace detail {
+// The handle-taking batch operations, shared by MontyField<LIMBS> and BoxedMontyField.
+struct DeviceOps {
+    const fpgpu_ctx* ctx;
+    void mul(const DeviceVec& a, const DeviceVec& b, DeviceVec& out) const { fpgpu_check(fpgpu_vec_mul(ctx, a.raw(), b.raw(), out.raw())); }
+    void add(const DeviceVec& a, const DeviceVec& b, DeviceVec& out) const { fpgpu_check(fpgpu_vec_add(ctx, a.raw(), b.raw(), out.raw())); }
+    void sub(const DeviceVec& a, const DeviceVec& b, DeviceVec& out) const { fpgpu_check(fpgpu_vec_sub(ctx, a.raw(), b.raw(), out.raw())); }
+    void neg(const DeviceVec& a, DeviceVec& out) const { fpgpu_check(fpgpu_vec_neg(ctx, a.raw(), out.raw())); }
+    void square(const DeviceVec& a, DeviceVec& out) const { fpgpu_check(fpgpu_vec_sqr(ctx, a.raw(), out.raw())); }
+    void project(const DeviceVec& a, DeviceVec& out) const { fpgpu_check(fpgpu_vec_to_mont(ctx, a.raw(), out.raw())); }
+    void lift(const DeviceVec& a, DeviceVec& out) const { fpgpu_check(fpgpu_vec_from_mont(ctx, a.raw(), out.raw())); }
+    void pow(const DeviceVec& a, const uint64_t* e, uint32_t words, DeviceVec& out) const {
+        fpgpu_check(fpgpu_vec_pow(ctx, a.raw(), e, words, out.raw()));
+    }
+    // flags[i] = 1 where the scalar inv returns None (out[i] = 0 there)
+    std::vector<uint8_t> inv(const DeviceVec& x, DeviceVec& out) const {
+        std::vector<uint8_t> none(x.size(), 0);
+        fpgpu_check(fpgpu_vec_batch_inv(ctx, x.raw(), out.raw(), none.data(), nullptr));
+        return none;
+    }
+    void matvec(const DeviceVec& A, size_t rows, size_t cols, const DeviceVec& x, DeviceVec& y) const {
+        fpgpu_check(fpgpu_vec_matvec(ctx, A.raw(), rows, cols, x.raw(), y.raw()));
+    }
+    void matmul(const DeviceVec& A, const DeviceVec& B, DeviceVec& C, size_t m, size_t k, size_t n) const {
+        fpgpu_check(fpgpu_vec_matmul(ctx, A.raw(), B.raw(), C.raw(), m, k, n));
+    }
+};
+}  // namespace detail
+
 // ---- MontyFieldElement<LIMBS> (repr(transparent) over Uint) ------------------------------
 template <size_t LIMBS>
 struct MontyFieldElement {
@@ -402,6 +461,42 @@ class MontyField {
         return y;
     }
 
+    // --- BATCH extension on device-resident vectors (fpgpu_vec): no host copy between calls -------
+    DeviceVec alloc_device(size_t n, Placement where = Placement::Current) const { return DeviceVec(ctx_.get(), n, where); }
+    DeviceVec alloc_device_rows(size_t rows, size_t cols, Placement where) const { return DeviceVec(ctx_.get(), rows * cols, where, cols); }
+    DeviceVec to_device(const std::vector<Element>& v, Placement where = Placement::Current, size_t row_len = 0) const {
+        DeviceVec d(ctx_.get(), v.size(), where, row_len);
+        if (!v.empty()) d.upload(p(v.data()), 0, v.size());
+        return d;
+    }
+    DeviceVec to_device(const DenseRowMatrix<Element>& A, Placement where) const { return to_device(A.data, where, A.num_cols); }
+    std::vector<Element> from_device(const DeviceVec& d) const {
+        std::vector<Element> v(d.size());
+        if (!v.empty()) d.download(p(v.data()), 0, v.size());
+        return v;
+    }
+    detail::DeviceOps on_device() const { return detail::DeviceOps{ctx_.get()}; }
+    void mul_batch(const DeviceVec& a, const DeviceVec& b, DeviceVec& out) const { on_device().mul(a, b, out); }
+    void add_batch(const DeviceVec& a, const DeviceVec& b, DeviceVec& out) const { on_device().add(a, b, out); }
+    void sub_batch(const DeviceVec& a, const DeviceVec& b, DeviceVec& out) const { on_device().sub(a, b, out); }
+    void neg_batch(const DeviceVec& a, DeviceVec& out) const { on_device().neg(a, out); }
+    void square_batch(const DeviceVec& a, DeviceVec& out) const { on_device().square(a, out); }
+    void pow_batch(const DeviceVec& a, const Integer& e, DeviceVec& out) const { on_device().pow(a, e.words.data(), (uint32_t)LIMBS, out); }
+    std::vector<uint8_t> inv_batch(const DeviceVec& x, DeviceVec& out) const { return on_device().inv(x, out); }
+    Element sum_batch(const DeviceVec& v) const { Element r; fpgpu_check(fpgpu_vec_sum(ctx_.get(), v.raw(), p(&r))); return r; }
+    Element product_batch(const DeviceVec& v) const { Element r; fpgpu_check(fpgpu_vec_product(ctx_.get(), v.raw(), p(&r))); return r; }
+    // sum_refs of mul over two slices (one row of the mat-vec)
+    Element dot_batch(const DeviceVec& a, const DeviceVec& b) const { Element r; fpgpu_check(fpgpu_vec_dot(ctx_.get(), a.raw(), b.raw(), p(&r))); return r; }
+    Element dot_batch(const std::vector<Element>& a, const std::vector<Element>& b) const {
+        if (a.size() != b.size()) throw std::invalid_argument("length mismatch");
+        Element r;
+        fpgpu_check(fpgpu_dot(ctx_.get(), p(a.data()), p(b.data()), a.size(), p(&r)));
+        return r;
+    }
+    // y = A x with A in row blocks over the device list, x whole on every device; a replicated y is all-gathered
+    void matvec(const DeviceVec& A, size_t rows, size_t cols, const DeviceVec& x, DeviceVec& y) const { on_device().matvec(A, rows, cols, x, y); }
+    void matmul(const DeviceVec& A, const DeviceVec& B, DeviceVec& C, size_t m, size_t k, size_t n) const { on_device().matmul(A, B, C, m, k, n); }
+
    private:
     static uint64_t* w(Element& e) { return e.v.words.data(); }
     static const uint64_t* w(const Element& e) { return e.v.words.data(); }
@@ -482,6 +577,25 @@ class BoxedMontyField {
             if (!none[i]) r[i] = Element{std::vector<uint64_t>(go.begin() + i * h_.n, go.begin() + (i + 1) * h_.n)};
         return r;
     }
+
+    // Device-resident form: the heap limbs are gathered ONCE into an fpgpu_vec; chains of batch
+    // operations then run with no per-element allocation and no host copy
+    // (the reference allocates per mul, crypto_bigint_boxed_monty.rs:182-196).
+    DeviceVec to_device(const std::vector<Element>& v, Placement where = Placement::Current) const {
+        DeviceVec d(ctx_.get(), v.size(), where);
+        std::vector<uint64_t> g = gather(v);
+        if (!v.empty()) d.upload(g.data(), 0, v.size());
+        return d;
+    }
+    DeviceVec alloc_device(size_t n, Placement where = Placement::Current) const { return DeviceVec(ctx_.get(), n, where); }
+    std::vector<Element> from_device(const DeviceVec& d) const {
+        std::vector<uint64_t> g(d.size() * h_.n);
+        if (d.size()) d.download(g.data(), 0, d.size());
+        std::vector<Element> out(d.size());
+        for (size_t i = 0; i < out.size(); i++) out[i].limbs.assign(g.begin() + i * h_.n, g.begin() + (i + 1) * h_.n);
+        return out;
+    }
+    detail::DeviceOps on_device() const { return detail::DeviceOps{ctx_.get()}; }
 
    private:
     std::vector<uint64_t> gather(const std::vector<Element>& v) const {

@@ -53,6 +53,7 @@ fn check(rc: i32) -> Result<(), GpuError> {
         sys::FPGPU_ERR_UNSUPPORTED => Err(GpuError::Unsupported(last_error())),
         sys::FPGPU_ERR_SHAPE => Err(GpuError::Shape(last_error())),
         sys::FPGPU_ERR_NO_DEVICE => Err(GpuError::NoDevice),
+        sys::FPGPU_ERR_RCCL => Err(GpuError::Hip(last_error())),
         _ => Err(GpuError::Hip(last_error())),
     }
 }
@@ -175,6 +176,18 @@ pub trait BatchFieldConfig: GpuMarshal {
     fn product_batch(&self, v: &[Self::Element]) -> Result<Self::Element, GpuError> {
         fold(self, v, sys::fpgpu_product)
     }
+    /// `sum_refs` (src/semiring.rs:213-226) of `mul` over two slices: a dot product.
+    fn dot_batch(&self, a: &[Self::Element], b: &[Self::Element]) -> Result<Self::Element, GpuError> {
+        if a.len() != b.len() {
+            return Err(GpuError::Shape("operand lengths differ".into()));
+        }
+        let ctx = self.gpu_ctx()?;
+        let (aw, bw) = (self.gather(a), self.gather(b));
+        let mut ow = vec![0u64; self.n64()];
+        // Safety: `aw`, `bw` hold a.len() elements, `ow` one.
+        check(unsafe { sys::fpgpu_dot(ctx.ptr(), aw.as_ptr(), bw.as_ptr(), a.len(), ow.as_mut_ptr()) })?;
+        Ok(self.read_words(&ow))
+    }
     /// `y[i] = sum_refs_j mul(A[i][j], x[j])` over `DenseRowMatrix::as_rows` (src/matrix.rs:162-164).
     fn matvec(&self, a: &DenseRowMatrix<Self::Element>, x: &[Self::Element]) -> Result<Vec<Self::Element>, GpuError> {
         if x.len() != a.num_cols || a.data.len() != a.num_rows * a.num_cols {
@@ -225,6 +238,188 @@ pub trait BatchFieldConfig: GpuMarshal {
     }
 }
 impl<T: GpuMarshal> BatchFieldConfig for T {}
+
+// ---- device-resident vectors: the fast path behind the trait ---------------------------------
+// A host-slice batch call pays PCIe for every operand of every call (and, for BoxedMontyField, a
+// gather over one heap allocation per element, src/field/crypto_bigint_boxed_monty.rs:62-64).  A
+// `DeviceVec` keeps the elements in HBM between calls: gather + upload once, chain any number of
+// batch operations with no host copy, download + scatter once.  `Placement` lays the vector out
+// over the device list of `set_devices`: contiguous ranges for elementwise work and inversion (no
+// collective), whole rows per device for the matrix products -- the reference's own parallel axis,
+// rayon over `par_chunks_exact(num_cols)` (src/matrix.rs:170-184) -- with an RCCL all-gather when
+// the output is replicated.
+
+/// Where a `DeviceVec` lives.
+#[derive(Debug, Clone, Copy, PartialEq, Eq)]
+pub enum Placement {
+    /// The calling thread's current HIP device.
+    Current,
+    /// Device `i`.
+    Device(u32),
+    /// Contiguous, balanced ranges (whole rows with `alloc_rows`) over the device list.
+    Sharded,
+    /// One full copy on every device of the list.
+    Replicated,
+}
+impl Placement {
+    fn raw(self) -> i32 {
+        match self {
+            Placement::Current => sys::FPGPU_PLACE_CURRENT,
+            Placement::Device(i) => i as i32,
+            Placement::Sharded => sys::FPGPU_PLACE_SHARDED,
+            Placement::Replicated => sys::FPGPU_PLACE_REPLICATED,
+        }
+    }
+}
+
+/// The device list that sharded / replicated vectors use (`&[]` returns to "current device alone").
+pub fn set_devices(ids: &[i32]) -> Result<(), GpuError> {
+    // Safety: `ids` holds `len` device indices.
+    check(unsafe { sys::fpgpu_set_devices(ids.as_ptr(), ids.len() as i32) })
+}
+
+/// Owning handle of an `fpgpu_vec`.  Operations on it are asynchronous on the library's
+/// per-device streams; `download` and the value-returning calls synchronise.
+pub struct DeviceVec {
+    raw: NonNull<sys::fpgpu_vec>,
+}
+unsafe impl Send for DeviceVec {}
+
+impl DeviceVec {
+    pub fn alloc(ctx: &GpuCtx, n: usize, place: Placement) -> Result<Self, GpuError> {
+        let mut raw = core::ptr::null_mut();
+        // Safety: `raw` receives an owned vector or stays null.
+        check(unsafe { sys::fpgpu_vec_alloc(ctx.ptr(), n, place.raw(), &mut raw) })?;
+        Ok(Self { raw: NonNull::new(raw).expect("fpgpu_vec_alloc returned OK and a null vector") })
+    }
+    /// `rows * cols` elements; a sharded placement gives every device whole rows.
+    pub fn alloc_rows(ctx: &GpuCtx, rows: usize, cols: usize, place: Placement) -> Result<Self, GpuError> {
+        let mut raw = core::ptr::null_mut();
+        check(unsafe { sys::fpgpu_vec_alloc_rows(ctx.ptr(), rows, cols, place.raw(), &mut raw) })?;
+        Ok(Self { raw: NonNull::new(raw).expect("fpgpu_vec_alloc_rows returned OK and a null vector") })
+    }
+    pub fn len(&self) -> usize {
+        unsafe { sys::fpgpu_vec_len(self.raw.as_ptr()) }
+    }
+    pub fn is_empty(&self) -> bool {
+        self.len() == 0
+    }
+    /// `words`: `n * n64` little-endian words (the output of `GpuMarshal::gather`).
+    pub fn upload_words(&mut self, words: &[u64], first: usize, n: usize) -> Result<(), GpuError> {
+        check(unsafe { sys::fpgpu_vec_upload(self.raw.as_ptr(), words.as_ptr(), first, n) })
+    }
+    pub fn download_words(&self, words: &mut [u64], first: usize, n: usize) -> Result<(), GpuError> {
+        check(unsafe { sys::fpgpu_vec_download(self.raw.as_ptr(), words.as_mut_ptr(), first, n) })
+    }
+    pub fn sync(&self) -> Result<(), GpuError> {
+        check(unsafe { sys::fpgpu_vec_sync(self.raw.as_ptr()) })
+    }
+    /// `self <- src` between any two layouts of the same length (scatter, all-gather, re-shard).
+    pub fn copy_from(&mut self, src: &DeviceVec) -> Result<(), GpuError> {
+        check(unsafe { sys::fpgpu_vec_copy(self.raw.as_ptr(), src.raw.as_ptr()) })
+    }
+    fn ptr(&self) -> *const sys::fpgpu_vec {
+        self.raw.as_ptr()
+    }
+    fn ptr_mut(&mut self) -> *mut sys::fpgpu_vec {
+        self.raw.as_ptr()
+    }
+}
+impl Drop for DeviceVec {
+    fn drop(&mut self) {
+        // Safety: created by fpgpu_vec_alloc*, freed once (the library waits for queued work first).
+        unsafe { sys::fpgpu_vec_free(self.raw.as_ptr()) }
+    }
+}
+
+type VBin = unsafe extern "C" fn(*const sys::fpgpu_ctx, *const sys::fpgpu_vec, *const sys::fpgpu_vec, *mut sys::fpgpu_vec) -> i32;
+type VUn = unsafe extern "C" fn(*const sys::fpgpu_ctx, *const sys::fpgpu_vec, *mut sys::fpgpu_vec) -> i32;
+
+/// `BatchFieldConfig` on device-resident vectors.  One context per chain (`gpu_ctx()` once), the
+/// same reference methods as the slice-level trait, no host copies between calls.
+pub trait DeviceBatchFieldConfig: GpuMarshal {
+    /// Gather the elements' words once and upload them.
+    fn to_device(&self, ctx: &GpuCtx, v: &[Self::Element], place: Placement) -> Result<DeviceVec, GpuError> {
+        let mut d = DeviceVec::alloc(ctx, v.len(), place)?;
+        d.upload_words(&self.gather(v), 0, v.len())?;
+        Ok(d)
+    }
+    /// `DenseRowMatrix::data` (src/matrix.rs:135-145) with whole rows per device.
+    fn matrix_to_device(&self, ctx: &GpuCtx, a: &DenseRowMatrix<Self::Element>, place: Placement) -> Result<DeviceVec, GpuError> {
+        let mut d = DeviceVec::alloc_rows(ctx, a.num_rows, a.num_cols, place)?;
+        d.upload_words(&self.gather(&a.data), 0, a.data.len())?;
+        Ok(d)
+    }
+    /// Download and scatter back into elements.
+    fn from_device(&self, d: &DeviceVec) -> Result<Vec<Self::Element>, GpuError> {
+        let mut w = vec![0u64; d.len() * self.n64()];
+        d.download_words(&mut w, 0, d.len())?;
+        Ok(self.scatter(&w))
+    }
+    fn mul_dev(&self, ctx: &GpuCtx, a: &DeviceVec, b: &DeviceVec, out: &mut DeviceVec) -> Result<(), GpuError> {
+        vbinary(ctx, a, b, out, sys::fpgpu_vec_mul)
+    }
+    fn add_dev(&self, ctx: &GpuCtx, a: &DeviceVec, b: &DeviceVec, out: &mut DeviceVec) -> Result<(), GpuError> {
+        vbinary(ctx, a, b, out, sys::fpgpu_vec_add)
+    }
+    fn sub_dev(&self, ctx: &GpuCtx, a: &DeviceVec, b: &DeviceVec, out: &mut DeviceVec) -> Result<(), GpuError> {
+        vbinary(ctx, a, b, out, sys::fpgpu_vec_sub)
+    }
+    fn neg_dev(&self, ctx: &GpuCtx, a: &DeviceVec, out: &mut DeviceVec) -> Result<(), GpuError> {
+        vunary(ctx, a, out, sys::fpgpu_vec_neg)
+    }
+    fn square_dev(&self, ctx: &GpuCtx, a: &DeviceVec, out: &mut DeviceVec) -> Result<(), GpuError> {
+        vunary(ctx, a, out, sys::fpgpu_vec_sqr)
+    }
+    /// `pow` with one exponent for the whole vector.
+    fn pow_dev(&self, ctx: &GpuCtx, a: &DeviceVec, e: &Self::Integer, out: &mut DeviceVec) -> Result<(), GpuError> {
+        let ew = self.integer_words(e);
+        check(unsafe { sys::fpgpu_vec_pow(ctx.ptr(), a.ptr(), ew.as_ptr(), ew.len() as u32, out.ptr_mut()) })
+    }
+    /// `inv` on every element; the returned flags are 1 exactly where the scalar method returns
+    /// `None` (`out[i]` is zero there).  Every device inverts its own range: no collective.
+    fn inv_dev(&self, ctx: &GpuCtx, x: &DeviceVec, out: &mut DeviceVec) -> Result<Vec<bool>, GpuError> {
+        let mut none = vec![0u8; x.len()];
+        check(unsafe { sys::fpgpu_vec_batch_inv(ctx.ptr(), x.ptr(), out.ptr_mut(), none.as_mut_ptr(), core::ptr::null_mut()) })?;
+        Ok(none.into_iter().map(|f| f != 0).collect())
+    }
+    fn sum_dev(&self, ctx: &GpuCtx, v: &DeviceVec) -> Result<Self::Element, GpuError> {
+        let mut w = vec![0u64; self.n64()];
+        check(unsafe { sys::fpgpu_vec_sum(ctx.ptr(), v.ptr(), w.as_mut_ptr()) })?;
+        Ok(self.read_words(&w))
+    }
+    fn product_dev(&self, ctx: &GpuCtx, v: &DeviceVec) -> Result<Self::Element, GpuError> {
+        let mut w = vec![0u64; self.n64()];
+        check(unsafe { sys::fpgpu_vec_product(ctx.ptr(), v.ptr(), w.as_mut_ptr()) })?;
+        Ok(self.read_words(&w))
+    }
+    /// `sum_refs` of `mul` over two vectors: one row of the mat-vec.
+    fn dot_dev(&self, ctx: &GpuCtx, a: &DeviceVec, b: &DeviceVec) -> Result<Self::Element, GpuError> {
+        let mut w = vec![0u64; self.n64()];
+        check(unsafe { sys::fpgpu_vec_dot(ctx.ptr(), a.ptr(), b.ptr(), w.as_mut_ptr()) })?;
+        Ok(self.read_words(&w))
+    }
+    /// `y = A x`: A in row blocks (from `matrix_to_device(.., Placement::Sharded)`), `x` whole on
+    /// every device (`Replicated`), `y` sharded like A's rows (no communication) or `Replicated`
+    /// (all-gather of the row blocks over xGMI).
+    fn matvec_dev(&self, ctx: &GpuCtx, a: &DeviceVec, rows: usize, cols: usize, x: &DeviceVec, y: &mut DeviceVec)
+                  -> Result<(), GpuError> {
+        check(unsafe { sys::fpgpu_vec_matvec(ctx.ptr(), a.ptr(), rows, cols, x.ptr(), y.ptr_mut()) })
+    }
+    fn matmul_dev(&self, ctx: &GpuCtx, a: &DeviceVec, b: &DeviceVec, c: &mut DeviceVec, m: usize, k: usize, n: usize)
+                  -> Result<(), GpuError> {
+        check(unsafe { sys::fpgpu_vec_matmul(ctx.ptr(), a.ptr(), b.ptr(), c.ptr_mut(), m, k, n) })
+    }
+}
+impl<T: GpuMarshal> DeviceBatchFieldConfig for T {}
+
+fn vbinary(ctx: &GpuCtx, a: &DeviceVec, b: &DeviceVec, out: &mut DeviceVec, f: VBin) -> Result<(), GpuError> {
+    // Safety: three live vectors of one context's element width; layouts are checked by the library.
+    check(unsafe { f(ctx.ptr(), a.ptr(), b.ptr(), out.ptr_mut()) })
+}
+fn vunary(ctx: &GpuCtx, a: &DeviceVec, out: &mut DeviceVec, f: VUn) -> Result<(), GpuError> {
+    check(unsafe { f(ctx.ptr(), a.ptr(), out.ptr_mut()) })
+}
 
 type Bin = unsafe extern "C" fn(*const sys::fpgpu_ctx, *const u64, *const u64, *mut u64, usize) -> i32;
 type Un = unsafe extern "C" fn(*const sys::fpgpu_ctx, *const u64, *mut u64, usize) -> i32;
@@ -377,6 +572,36 @@ mod tests {
             assert_eq!(inv[i], f.inv(v));
         }
         assert!(inv[7].is_none());
+    }
+
+    #[test]
+    fn device_chain_equals_scalar() {
+        // a*b + a, squared, inverted: three dependent batch operations on HBM-resident vectors,
+        // one upload per operand and one download; sharded over a list that names GPU 0 twice
+        let f = field();
+        let ctx = f.gpu_ctx().unwrap();
+        let a: Vec<_> = (1u64..500).map(|v| f.project(&v.wrapping_mul(0x9E3779B97F4A7C15))).collect();
+        let b: Vec<_> = (1u64..500).map(|v| f.project(&v.wrapping_mul(0xBF58476D1CE4E5B9))).collect();
+        for ids in [&[][..], &[0][..], &[0, 0][..]] {
+            set_devices(ids).unwrap();
+            let place = if ids.is_empty() { Placement::Current } else { Placement::Sharded };
+            let (da, db) = (f.to_device(&ctx, &a, place).unwrap(), f.to_device(&ctx, &b, place).unwrap());
+            let mut t = DeviceVec::alloc(&ctx, a.len(), place).unwrap();
+            let mut u = DeviceVec::alloc(&ctx, a.len(), place).unwrap();
+            f.mul_dev(&ctx, &da, &db, &mut t).unwrap();
+            f.add_dev(&ctx, &t, &da, &mut u).unwrap();
+            f.square_dev(&ctx, &u, &mut t).unwrap();
+            let none = f.inv_dev(&ctx, &t, &mut u).unwrap();
+            let got = f.from_device(&u).unwrap();
+            for i in 0..a.len() {
+                let s = f.add(&f.mul(&a[i], &b[i]), &a[i]);
+                let want = f.inv(&f.mul(&s, &s));
+                assert_eq!(none[i], want.is_none());
+                assert_eq!(got[i], want.unwrap_or_else(|| f.zero()));
+            }
+            assert_eq!(f.dot_dev(&ctx, &da, &db).unwrap(), f.dot_batch(&a, &b).unwrap());
+        }
+        set_devices(&[]).unwrap();
     }
 
     #[test]

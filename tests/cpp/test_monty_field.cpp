@@ -252,6 +252,70 @@ static void test_gpu_batches() {
     CHECK(!binv[0].has_value());
     for (size_t i = 1; i < 500; i++) CHECK(binv[i].has_value() && bf.mul(*binv[i], bb[i]) == bf.one());
 }
+// ---- GPU: device-resident vectors -- chains with no host copy, sharded over a device list -------
+static void test_gpu_device_vectors() {
+    auto f = F256::new_(Uint<4>::from_be_hex("30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001"));
+    const size_t n = 5003;
+    std::vector<F256::Element> a(n), b(n);
+    for (size_t i = 0; i < n; i++) { a[i] = f.project((uint64_t)(i * 2654435761u + 12345)); b[i] = f.project((uint64_t)((i + 7) * 0x9E3779B97F4A7C15ull)); }
+    a[11] = f.zero();
+    for (int layout = 0; layout < 3; layout++) {
+        if (layout == 1) set_devices({0});
+        if (layout == 2) set_devices({0, 0, 0});
+        const Placement where = layout == 0 ? Placement::Current : Placement::Sharded;
+        DeviceVec da = f.to_device(a, where), db = f.to_device(b, where);
+        DeviceVec t = f.alloc_device(n, where), u = f.alloc_device(n, where), v = f.alloc_device(n, where);
+        f.mul_batch(da, db, t);          // t = a b
+        f.add_batch(t, da, u);           // u = a b + a
+        f.square_batch(u, t);            // t = u^2
+        auto none = f.inv_batch(t, v);   // v = 1 / t   (None where t = 0)
+        f.sub_batch(v, db, u);           // u = v - b
+        auto got = f.from_device(u);
+        size_t bad = 0;
+        for (size_t i = 0; i < n; i++) {
+            auto ti = f.mul(f.add(f.mul(a[i], b[i]), a[i]), f.add(f.mul(a[i], b[i]), a[i]));
+            auto inv = f.inv(ti);
+            if (none[i] != (inv ? 0 : 1)) bad++;
+            auto want = f.sub(inv ? *inv : f.zero(), b[i]);
+            if (!(got[i] == want)) bad++;
+        }
+        CHECK(bad == 0);
+        CHECK(none[11] == 1);
+        CHECK(f.sum_batch(da) == f.sum_refs(a.begin(), a.end()));
+        CHECK(f.product_batch(db) == f.product_refs(b.begin(), b.end()));
+        F256::Element dot = f.zero();
+        for (size_t i = 0; i < n; i++) dot = f.add(dot, f.mul(a[i], b[i]));
+        CHECK(f.dot_batch(da, db) == dot);
+        CHECK(f.dot_batch(a, b) == dot);
+        // row-sharded mat-vec, x replicated, y all-gathered (RCCL for the list of one, peer copies for the repeated GPU)
+        const size_t rows = 37, cols = 64;
+        DenseRowMatrix<F256::Element> A;
+        A.num_rows = rows; A.num_cols = cols; A.data.assign(a.begin(), a.begin() + rows * cols);
+        std::vector<F256::Element> x(b.begin(), b.begin() + cols);
+        DeviceVec dA = f.to_device(A, where), dx = f.to_device(x, layout == 0 ? Placement::Current : Placement::Replicated);
+        DeviceVec dy = f.alloc_device(rows, layout == 0 ? Placement::Current : Placement::Replicated);
+        f.matvec(dA, rows, cols, dx, dy);
+        CHECK(f.from_device(dy) == f.matvec(A, x));
+    }
+    set_devices({});
+    // BoxedMontyField: limbs gathered once, chain on the device, scattered once
+    auto bf = BoxedMontyField::new_({0xB9FEFFFFFFFFAAABull, 0x1EABFFFEB153FFFFull, 0x6730D2A0F6B0F624ull, 0x64774B84F38512BFull,
+                                     0x4B1BA7B6434BACD7ull, 0x1A0111EA397FE69Aull});
+    std::vector<BoxedMontyField::Element> ba, bb;
+    for (uint64_t i = 0; i < 300; i++) { ba.push_back(bf.project(i * 77 + 3)); bb.push_back(bf.project(i * i + 1)); }
+    DeviceVec xa = bf.to_device(ba), xb = bf.to_device(bb), xt = bf.alloc_device(300), xu = bf.alloc_device(300);
+    bf.on_device().mul(xa, xb, xt);
+    bf.on_device().add(xt, xb, xu);
+    auto none = bf.on_device().inv(xu, xt);
+    auto res = bf.from_device(xt);
+    size_t bad = 0;
+    for (size_t i = 0; i < 300; i++) {
+        auto inv = bf.inv(bf.add(bf.mul(ba[i], bb[i]), bb[i]));
+        if (!inv || none[i] || !(res[i] == *inv)) bad++;
+    }
+    CHECK(bad == 0);
+}
+
 static void test_no_device_is_an_error_not_a_fallback() {
     if (fpgpu_device_count() > 0) return;
     F f = make_f();
@@ -274,7 +338,7 @@ int main(int argc, char** argv) {
     test_const_monty_element_style();
     test_boxed_scalar();
     test_no_device_is_an_error_not_a_fallback();
-    if (mode == "gpu") test_gpu_batches();
+    if (mode == "gpu") { test_gpu_batches(); test_gpu_device_vectors(); }
     std::printf("%s: %d checks, %d failures\n", mode.c_str(), g_checks, g_fail);
     return g_fail ? 1 : 0;
 }
