@@ -99,6 +99,8 @@ class MontyField:
 
     def mul_chain(self, a, b, iters):
         a, b = _np(a, self.n64), _np(b, self.n64)
+        if a.shape != b.shape:
+            raise ValueError("operand length mismatch")
         out = np.empty_like(a)
         check(self._lib.fpgpu_mul_chain(self._h, _ptr(a), _ptr(b), _ptr(out), a.shape[0], iters))
         return out
@@ -238,10 +240,31 @@ class MontyField:
         import torch
         return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
-    def _chk_t(self, t):
-        if not t.is_cuda or not t.is_contiguous() or t.element_size() != 8 or t.shape[-1] != self.n64:
-            raise ValueError("expected a contiguous CUDA tensor of 8-byte words with last dim n64")
+    def _chk_t(self, t, count=None, name="tensor"):
+        """Device pointer of `t` after checking what the kernels assume: a contiguous CUDA tensor of 8-byte
+        words with last dimension n64, on the current HIP device (whose stream the launch uses), holding
+        exactly `count` elements when a count is given."""
+        import torch
+        if not t.is_cuda or not t.is_contiguous() or t.element_size() != 8 or t.dim() < 1 or t.shape[-1] != self.n64:
+            raise ValueError("%s: expected a contiguous CUDA tensor of 8-byte words with last dim n64" % name)
+        if t.device.index != torch.cuda.current_device():
+            raise ValueError("%s lives on cuda:%d but the current device is cuda:%d" % (name, t.device.index, torch.cuda.current_device()))
+        if count is not None and t.numel() != count * self.n64:
+            raise ValueError("%s holds %d elements, expected %d" % (name, t.numel() // self.n64, count))
         return ctypes.c_void_p(t.data_ptr())
+
+    @staticmethod
+    def _chk_bytes(t, nbytes, name):
+        """Device pointer and byte size of a raw buffer (flags, workspace) of at least `nbytes` bytes."""
+        import torch
+        if not t.is_cuda or not t.is_contiguous():
+            raise ValueError("%s: expected a contiguous CUDA tensor" % name)
+        if t.device.index != torch.cuda.current_device():
+            raise ValueError("%s lives on cuda:%d but the current device is cuda:%d" % (name, t.device.index, torch.cuda.current_device()))
+        have = t.numel() * t.element_size()
+        if have < nbytes:
+            raise ValueError("%s holds %d bytes, needs %d" % (name, have, nbytes))
+        return ctypes.c_void_p(t.data_ptr()), have
 
     def alloc(self, n, device=None):
         import torch
@@ -249,56 +272,75 @@ class MontyField:
 
     def random_dev(self, n, seed, device=None):
         t = self.alloc(n, device)
-        check(self._lib.fpgpu_fill_random_dev(self._h, self._chk_t(t), n, seed, self._stream()))
+        check(self._lib.fpgpu_fill_random_dev(self._h, self._chk_t(t, n, "out"), n, seed, self._stream()))
         return t
 
-    def mul_dev(self, a, b, out):
-        check(self._lib.fpgpu_mul_dev(self._h, self._chk_t(a), self._chk_t(b), self._chk_t(out), a.shape[0], self._stream()))
+    def _bin_dev(self, fn, a, b, out):
+        n = a.numel() // self.n64
+        check(fn(self._h, self._chk_t(a, n, "a"), self._chk_t(b, n, "b"), self._chk_t(out, n, "out"), n, self._stream()))
         return out
 
-    def add_dev(self, a, b, out):
-        check(self._lib.fpgpu_add_dev(self._h, self._chk_t(a), self._chk_t(b), self._chk_t(out), a.shape[0], self._stream()))
+    def _un_dev(self, fn, a, out):
+        n = a.numel() // self.n64
+        check(fn(self._h, self._chk_t(a, n, "a"), self._chk_t(out, n, "out"), n, self._stream()))
         return out
 
-    def sub_dev(self, a, b, out):
-        check(self._lib.fpgpu_sub_dev(self._h, self._chk_t(a), self._chk_t(b), self._chk_t(out), a.shape[0], self._stream()))
-        return out
-
-    def sqr_dev(self, a, out):
-        check(self._lib.fpgpu_sqr_dev(self._h, self._chk_t(a), self._chk_t(out), a.shape[0], self._stream()))
-        return out
-
-    def neg_dev(self, a, out):
-        check(self._lib.fpgpu_neg_dev(self._h, self._chk_t(a), self._chk_t(out), a.shape[0], self._stream()))
-        return out
-
-    def to_mont_dev(self, a, out):
-        check(self._lib.fpgpu_to_mont_dev(self._h, self._chk_t(a), self._chk_t(out), a.shape[0], self._stream()))
-        return out
-
-    def from_mont_dev(self, a, out):
-        check(self._lib.fpgpu_from_mont_dev(self._h, self._chk_t(a), self._chk_t(out), a.shape[0], self._stream()))
-        return out
+    def mul_dev(self, a, b, out): return self._bin_dev(self._lib.fpgpu_mul_dev, a, b, out)
+    def add_dev(self, a, b, out): return self._bin_dev(self._lib.fpgpu_add_dev, a, b, out)
+    def sub_dev(self, a, b, out): return self._bin_dev(self._lib.fpgpu_sub_dev, a, b, out)
+    def sqr_dev(self, a, out): return self._un_dev(self._lib.fpgpu_sqr_dev, a, out)
+    def neg_dev(self, a, out): return self._un_dev(self._lib.fpgpu_neg_dev, a, out)
+    def to_mont_dev(self, a, out): return self._un_dev(self._lib.fpgpu_to_mont_dev, a, out)
+    def from_mont_dev(self, a, out): return self._un_dev(self._lib.fpgpu_from_mont_dev, a, out)
 
     def mul_chain_dev(self, a, b, out, iters):
-        check(self._lib.fpgpu_mul_chain_dev(self._h, self._chk_t(a), self._chk_t(b), self._chk_t(out), a.shape[0], iters, self._stream()))
+        n = a.numel() // self.n64
+        check(self._lib.fpgpu_mul_chain_dev(self._h, self._chk_t(a, n, "a"), self._chk_t(b, n, "b"), self._chk_t(out, n, "out"),
+                                            n, iters, self._stream()))
         return out
+
+    def pow_dev(self, a, exponent: int, out):
+        n = a.numel() // self.n64
+        nw = max(1, (exponent.bit_length() + 63) // 64)
+        ew = np.array([(exponent >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(nw)], dtype=np.uint64)
+        check(self._lib.fpgpu_pow_dev(self._h, self._chk_t(a, n, "a"), _ptr(ew), nw, self._chk_t(out, n, "out"), n, self._stream()))
+        return out
+
+    def fold_workspace_bytes(self):
+        return int(self._lib.fpgpu_fold_workspace_bytes(self._h))
+
+    def _fold_dev(self, fn, operands, n, out, workspace):
+        wp, wb = (None, 0) if workspace is None else self._chk_bytes(workspace, self.fold_workspace_bytes() if n > 256 else 0, "workspace")
+        if n > 256 and workspace is None:
+            raise ValueError("workspace needed for more than 256 elements (fold_workspace_bytes())")
+        ptrs = [self._chk_t(t, n, "operand") for t in operands]
+        check(fn(self._h, *ptrs, n, self._chk_t(out, 1, "out"), wp, wb, self._stream()))
+        return out
+
+    def sum_dev(self, v, out, workspace=None): return self._fold_dev(self._lib.fpgpu_sum_dev, [v], v.numel() // self.n64, out, workspace)
+    def product_dev(self, v, out, workspace=None): return self._fold_dev(self._lib.fpgpu_product_dev, [v], v.numel() // self.n64, out, workspace)
+
+    def dot_dev(self, a, b, out, workspace=None):
+        """out[0] = sum_i mul(a[i], b[i]) (fpgpu_dot_dev)."""
+        return self._fold_dev(self._lib.fpgpu_dot_dev, [a, b], a.numel() // self.n64, out, workspace)
 
     def inv_workspace_bytes(self, n):
         return self._lib.fpgpu_batch_inv_workspace_bytes(self._h, n)
 
     def inv_dev(self, x, out, flags, workspace):
-        fp = ctypes.c_void_p(flags.data_ptr()) if flags is not None else None
-        check(self._lib.fpgpu_batch_inv_dev(self._h, self._chk_t(x), self._chk_t(out), fp, x.shape[0],
-                                            ctypes.c_void_p(workspace.data_ptr()), workspace.numel() * workspace.element_size(),
+        n = x.numel() // self.n64
+        fp = self._chk_bytes(flags, n, "flags")[0] if flags is not None else None
+        wp, wb = self._chk_bytes(workspace, self.inv_workspace_bytes(n), "workspace")
+        check(self._lib.fpgpu_batch_inv_dev(self._h, self._chk_t(x, n, "x"), self._chk_t(out, n, "out"), fp, n, wp, wb,
                                             self._stream()))
         return out
 
     def inv_static_dev(self, x, out, flags):
         """fpgpu_batch_inv_static_dev: batch inversion that allocates nothing and takes no workspace (the
         library's static device array); same results as inv_dev."""
-        fp = ctypes.c_void_p(flags.data_ptr()) if flags is not None else None
-        check(self._lib.fpgpu_batch_inv_static_dev(self._h, self._chk_t(x), self._chk_t(out), fp, x.shape[0], self._stream()))
+        n = x.numel() // self.n64
+        fp = self._chk_bytes(flags, n, "flags")[0] if flags is not None else None
+        check(self._lib.fpgpu_batch_inv_static_dev(self._h, self._chk_t(x, n, "x"), self._chk_t(out, n, "out"), fp, n, self._stream()))
         return out
 
     def matvec_workspace_bytes(self, rows, cols):
@@ -309,20 +351,19 @@ class MontyField:
         the products run on the matrix cores (same results)."""
         wp, wb = None, 0
         if workspace is not None:
-            wp, wb = ctypes.c_void_p(workspace.data_ptr()), workspace.numel() * workspace.element_size()
-        check(self._lib.fpgpu_matvec_dev(self._h, self._chk_t(A), rows, cols, self._chk_t(x), self._chk_t(y), wp, wb,
-                                         self._stream()))
+            wp, wb = self._chk_bytes(workspace, 0, "workspace")
+        check(self._lib.fpgpu_matvec_dev(self._h, self._chk_t(A, rows * cols, "A"), rows, cols, self._chk_t(x, cols, "x"),
+                                         self._chk_t(y, rows, "y"), wp, wb, self._stream()))
         return y
 
     def spmv_dev(self, vals, col_idx, rows, cols, density, x, y):
         """SparseMatrix (fixed `density` cells per row) times vector on device tensors; col_idx is a
         contiguous 4-byte integer CUDA tensor of rows*density column indices (< cols)."""
-        if not col_idx.is_cuda or not col_idx.is_contiguous() or col_idx.element_size() != 4 or col_idx.numel() != rows * density:
+        if col_idx.element_size() != 4 or col_idx.numel() != rows * density:
             raise ValueError("expected a contiguous CUDA tensor of rows*density 4-byte column indices")
-        if vals.shape[0] != rows * density or x.shape[0] != cols or y.shape[0] != rows:
-            raise ValueError("sparse matrix / vector shape mismatch")
-        check(self._lib.fpgpu_spmv_dev(self._h, self._chk_t(vals), ctypes.c_void_p(col_idx.data_ptr()), rows, cols, density,
-                                       self._chk_t(x), self._chk_t(y), self._stream()))
+        cp, _ = self._chk_bytes(col_idx, rows * density * 4, "col_idx")
+        check(self._lib.fpgpu_spmv_dev(self._h, self._chk_t(vals, rows * density, "vals"), cp, rows, cols, density,
+                                       self._chk_t(x, cols, "x"), self._chk_t(y, rows, "y"), self._stream()))
         return y
 
     def matmul_workspace_bytes(self, m, k, n):
@@ -333,7 +374,7 @@ class MontyField:
         single-limb fields run on the matrix cores (same results)."""
         wp, wb = None, 0
         if workspace is not None:
-            wp, wb = ctypes.c_void_p(workspace.data_ptr()), workspace.numel() * workspace.element_size()
-        check(self._lib.fpgpu_matmul_dev(self._h, self._chk_t(A), self._chk_t(B), self._chk_t(C), m, k, n, wp, wb,
-                                         self._stream()))
+            wp, wb = self._chk_bytes(workspace, 0, "workspace")
+        check(self._lib.fpgpu_matmul_dev(self._h, self._chk_t(A, m * k, "A"), self._chk_t(B, k * n, "B"), self._chk_t(C, m * n, "C"),
+                                         m, k, n, wp, wb, self._stream()))
         return C

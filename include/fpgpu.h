@@ -16,7 +16,15 @@
  * no copy-in format: a `&[MontyFieldElement<LIMBS>]` can be passed as is.
  * All field elements are Montgomery representatives with R = 2^(64*n64), as in
  * the reference.  Results are canonical ([0, p)) and bit-identical to the
- * reference's.
+ * reference's for inputs that are field elements (< p).  Inputs outside the
+ * field: mul (a < R, b < p), sqr, to_mont (any n64-word value) and from_mont
+ * follow the reference's integer arithmetic exactly for every input -- the
+ * reference itself projects wide values this way (crypto_bigint_monty.rs:319-340).
+ * Everything else -- add, sub, neg, the chains, folds, dot, batch inversion, the
+ * matrix products (lazily reduced accumulators) -- is defined for canonical
+ * inputs only, as crypto-bigint's add_mod / sub_mod / neg_mod are.
+ * On a little-endian host this layout is also the elements' wire format (the
+ * reference's serde impls emit each element's little-endian bytes).
  *
  * Device pointers must be 16-byte aligned (8-byte for n64 odd).  Every *_dev
  * call is asynchronous on `stream` (a hipStream_t, NULL = default stream) of the
@@ -171,8 +179,9 @@ int fpgpu_dot_dev(const fpgpu_ctx *ctx, const void *a, const void *b, size_t n, 
                   size_t workspace_bytes, void *stream);
 
 /* ---- synthetic inputs -------------------------------
- * Fills `out` with n uniform elements in [0, p): word l of element i is
- * splitmix64(seed ^ (i*n64 + l)), the value masked to bitlen(p) bits, minus p once if >= p.
+ * Fills `out` with n near-uniform elements of [0, p): word l of element i is
+ * splitmix64(seed ^ (i*n64 + l)), the value masked to bitlen(p) bits, minus p once if >= p
+ * (so residues below 2^bitlen - p are twice as likely: synthetic bench input, not a sampler).
  * Identical to the host generator in bench.py / tests. */
 int fpgpu_fill_random_dev(const fpgpu_ctx *ctx, void *out, size_t n, uint64_t seed, void *stream);
 

@@ -182,7 +182,8 @@ def test_batch_inv_vs_oracle(cpa, n):
 @pytest.mark.parametrize("clen", ["2", "3", "32", "100"])
 def test_batch_inv_chain_lengths(cpa, clen, tuning):
     """The chain length per level is a tuning choice (FPGPU_INV_C pins it): every partition into
-    chains gives the same inverses, ragged last chains and many levels included."""
+    chains gives the same inverses, ragged last chains included (these sizes plan ONE level: the top
+    takes up to 65536 totals; multi-level plans are in test_batch_inv_multi_level_plans)."""
     tuning("FPGPU_INV_C", clen)
     for name, n in (("bls12_381_fq", 70001), ("bn254_fr", 40000), ("goldilocks", 100003), ("odd_composite_128", 6000)):
         g = load_golden(name)
@@ -589,7 +590,8 @@ def test_chain_kernels_tight_and_lazy_moduli(cpa, case):
     # pow (one exponent per batch)
     for e in (0, 1, 2, 65537, p - 2, rnd.getrandbits(64 * n64)):
         assert np.array_equal(f.pow(x, e), o.pow(x, e, exponent_bits=64 * n64)), hex(e)
-    # batch inversion with zeros, more than one level of chains
+    # batch inversion with zeros (one level of chains at this size; the multi-level plans are in
+    # test_batch_inv_multi_level_plans)
     big = ints_to_array([0 if i % 53 == 7 else rnd.randrange(p) for i in range(4500)], n64)
     got, flags = f.inv(big)
     want, wflags = o.batch_inv(big)
@@ -671,3 +673,105 @@ def test_forced_kernel_paths_agree(cpa, hook, tuning):
         x = ints_to_array(synth_elements(p, n64, k, 203), n64)
         wy = o.matvec(A, m, k, x, threads=0)
         assert np.array_equal(_dev_matvec(cpa, f, A, m, k, x, True).reshape(wy.shape), wy), gname
+
+
+@pytest.mark.parametrize("case", _UNSAT_MODULI, ids=[c[0] for c in _UNSAT_MODULI])
+def test_every_width_elementwise_fold_matvec_spmv(cpa, case):
+    """Every compiled width (n64 = 3, 5, 7, 8 included, tight and roomy moduli) through the kernels the
+    chain tests above do not reach: k_elementwise for all seven operations (the unsaturated
+    multiplier from 384 bits on), the sum fold, the dot product, k_spmv, and the mat-vec on both
+    paths -- matrix cores (NT = n64, up to the 512-thread expander at NT = 8) and VALU."""
+    from oracle.fp_oracle import Oracle
+    _, p, n64 = case
+    f, o = cpa.MontyField(p, n64), Oracle(p, n64)
+    rnd = random.Random(p % 999983)
+    edge = [0, 1, 2, p - 1, p - 2, p >> 1, (p >> 1) + 1]
+    for n in (1, 65, 1031):
+        xs = (edge + [rnd.randrange(p) for _ in range(n)])[:n]
+        ys = ([p - 1, 1, p - 2] + [rnd.randrange(p) for _ in range(n)])[:n]
+        a, b = ints_to_array(xs, n64), ints_to_array(ys, n64)
+        assert np.array_equal(f.mul(a, b), o.mul(a, b))
+        assert np.array_equal(f.sqr(a), o.sqr(a))
+        assert np.array_equal(f.add(a, b), o.add(a, b))
+        assert np.array_equal(f.sub(a, b), o.sub(a, b))
+        assert np.array_equal(f.neg(a), o.neg(a))
+        assert np.array_equal(f.lift(a), o.from_mont(a))
+        assert np.array_equal(f.sum(a), o.sum(a))
+        assert np.array_equal(f.dot(a, b), o.sum(o.mul(a, b)))
+        # project takes ANY n64-word value (also >= p), mul any a < R with b < p
+        R = 1 << (64 * n64)
+        wide = ints_to_array([R - 1, p, p + 1] + [rnd.randrange(R) for _ in range(n)], n64)[:n]
+        assert np.array_equal(f.project(wide), o.to_mont(wide))
+        assert np.array_equal(f.mul(wide, b), o.mul(wide, b))
+    # mat-vec: row bytes a multiple of 16 and >= 64 so that the matrix-core plan is usable
+    cols = 24 if n64 % 2 else 10
+    assert cols * 8 * n64 >= 64 and (cols * 8 * n64) % 16 == 0
+    for rows, cols_ in ((5, cols), (131, cols * 7), (3, 1)):
+        A = ints_to_array([rnd.choice((p - 1, rnd.randrange(p))) for _ in range(rows * cols_)], n64)
+        x = ints_to_array([rnd.choice((p - 1, p >> 1, rnd.randrange(p))) for _ in range(cols_)], n64)
+        want = o.matvec(A, rows, cols_, x, threads=0)
+        if cols_ > 1:
+            assert f.matvec_workspace_bytes(rows, cols_) > 0
+        assert np.array_equal(_dev_matvec(cpa, f, A, rows, cols_, x, True).reshape(want.shape), want), ("mfma", rows, cols_)
+        assert np.array_equal(_dev_matvec(cpa, f, A, rows, cols_, x, False).reshape(want.shape), want), ("valu", rows, cols_)
+        assert np.array_equal(f.matvec(A, rows, cols_, x), want)
+    rows, cols_, density = 37, 50, 6
+    vals = ints_to_array([rnd.randrange(p) for _ in range(rows * density)], n64)
+    x = ints_to_array([rnd.randrange(p) for _ in range(cols_)], n64)
+    col = np.random.default_rng(n64).integers(0, cols_, size=rows * density, dtype=np.uint32)
+    assert np.array_equal(f.spmv(vals, col, rows, cols_, density, x), o.spmv(vals, col, rows, cols_, density, x))
+
+
+@pytest.mark.parametrize("name,p,n64", [("bls12_381", 0x1A0111EA397FE69A4B1BA7B6434BACD764774B84F38512BF6730D2A0F6B0F6241EABFFFEB153FFFFB9FEFFFFFFFFAAAB, 6),
+                                        ("secp256k1 (tight)", 2**256 - 2**32 - 977, 4), ("p512 (tight)", 2**512 - 569, 8),
+                                        ("odd composite", 3 * (2**107 - 1), 2)])
+def test_batch_inv_multi_level_plans(cpa, name, p, n64, tuning):
+    """Chains of 2 make 140001 elements plan TWO levels of prefix products below the top (70001 and
+    35001 totals: k_binv_up / k_binv_down<N, false>, the per-level index map of the fallback kernel,
+    a poisoned group reaching the top through two levels), compared bit for bit with the oracle."""
+    from oracle.fp_oracle import Oracle
+    tuning("FPGPU_INV_C", 2)
+    f, o = cpa.MontyField(p, n64), Oracle(p, n64)
+    n = 140001
+    assert f.inv_workspace_bytes(n) > (n // 2 + n // 4) * 8 * n64       # two stored levels of totals
+    rnd = random.Random(n64)
+    xs = [rnd.randrange(1, p) for _ in range(n)]
+    for i in range(0, n, 997):
+        xs[i] = 0
+    xs[-1] = 0
+    if "composite" in name:
+        xs[5] = 3
+        xs[70000] = (2**107 - 1) * 5
+        xs[139999] = 9
+    x = ints_to_array(xs, n64)
+    got, flags = f.inv(x)
+    want, wflags = o.batch_inv(x)
+    assert np.array_equal(flags, wflags)
+    assert np.array_equal(got, want)
+    if "composite" in name:
+        assert flags[5] == 1 and flags[70000] == 1 and flags[139999] == 1 and flags[6] == 0
+
+
+def test_device_wrappers_validate_shapes(cpa):
+    """The Python device wrappers refuse operands whose element counts do not match what the kernel
+    will touch (a short `out` would otherwise be written past its end)."""
+    import torch
+    f = cpa.MontyField(cpa.BN254_FR, 4)
+    a, b = f.alloc(100), f.alloc(100)
+    with pytest.raises(ValueError, match="holds 99 elements"):
+        f.mul_dev(a, b, f.alloc(99))
+    with pytest.raises(ValueError, match="holds 99 elements"):
+        f.add_dev(a, f.alloc(99), b)
+    with pytest.raises(ValueError, match="holds"):
+        f.matvec_dev(a, 10, 11, f.alloc(11), f.alloc(10))
+    with pytest.raises(ValueError, match="holds"):
+        f.matmul_dev(a, b, f.alloc(99), 10, 10, 10)
+    with pytest.raises(ValueError, match="flags holds"):
+        f.inv_dev(a, b, torch.empty(50, dtype=torch.uint8, device="cuda"),
+                  torch.empty(f.inv_workspace_bytes(100), dtype=torch.uint8, device="cuda"))
+    with pytest.raises(ValueError, match="workspace holds"):
+        f.inv_dev(a, b, None, torch.empty(16, dtype=torch.uint8, device="cuda"))
+    with pytest.raises(ValueError, match="CUDA tensor"):
+        f.mul_dev(a.cpu(), b, a)
+    with pytest.raises(ValueError, match="operand length mismatch"):
+        f.mul_chain(np.ones((4, 4), dtype=np.uint64), np.ones((3, 4), dtype=np.uint64), 2)

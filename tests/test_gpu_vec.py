@@ -132,11 +132,8 @@ def test_dot_dev_edge_values_and_lengths(cpa):
             da = torch.from_numpy(ha.view(np.int64)).cuda()
             db = torch.from_numpy(hb.view(np.int64)).cuda()
             out = f.alloc(1)
-            ws = torch.empty(f._lib.fpgpu_fold_workspace_bytes(f._h), dtype=torch.uint8, device="cuda")
-            import ctypes
-            from crypto_primitives_amd._lib import check
-            check(f._lib.fpgpu_dot_dev(f._h, f._chk_t(da), f._chk_t(db), n, f._chk_t(out), ctypes.c_void_p(ws.data_ptr()),
-                                       ws.numel(), f._stream()))
+            ws = torch.empty(f.fold_workspace_bytes(), dtype=torch.uint8, device="cuda")
+            f.dot_dev(da, db, out, ws)
             torch.cuda.synchronize()
             assert np.array_equal(out.cpu().numpy().view(np.uint64)[0], o.sum(o.mul(ha, hb))), (name, n)
 
