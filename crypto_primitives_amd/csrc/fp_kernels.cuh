@@ -13,8 +13,12 @@ namespace fpgpu {
 // ones, from 384 bits on, where the saturated multiplier makes them VALU-bound (BLS12-381: sqr
 // 4.26 TB/s and mul 5.13 against 5.4 for add).  Up to 320 bits the saturated multiplier hides
 // behind the memory time; the unsaturated one was tried at 256 bits for the one-read-one-write
-// kernels (sqr 3.35 -> 3.74 ms, to_mont 3.20 -> 3.30 ms over 2^28 elements: the conversions
-// between words and limbs cost more than the carry adds saved) and is not used there.
+// kernels (round 1: sqr 3.35 -> 3.74 ms, to_mont 3.20 -> 3.30 ms over 2^28 elements; round 2, with R^2
+// as scalar limbs: to_mont 3.10 -> 3.23 ms although the kernel has 190 four-cycle instructions
+// instead of 275 -- one serial 64-bit column chain per lane overlaps worse with the loads than the
+// saturated mad / addc pairs) and is not used there.  At 256 bits sqr takes the symmetric saturated
+// square (mont_sqr: 36 limb products instead of 64) and to_mont multiplies by R^2 out of scalar
+// registers (mont_mul_const).
 template <int N, int OP>
 struct UnsatElementwise {
     static constexpr bool value = N >= 12 && (OP == OP_MUL || OP == OP_SQR || OP == OP_TO_MONT);
@@ -25,45 +29,55 @@ struct UnsatElementwise {
 // whole 4N-byte element with 16-byte loads; a wave covers 64 consecutive elements
 // (2 KiB at N = 8), so every fetched 128-byte line is fully consumed by the wave
 // that touched it (measured 5.3 TB/s on the 2R+1W pattern, profiles/).
+// One elementwise operation on registers (shared by every shape of the streaming kernel).
+template <int N, int OP>
+__device__ __forceinline__ void elementwise_op(uint32_t (&r)[N], const uint32_t (&x)[N], const uint32_t (&y)[N],
+                                               const FpParams<N>& P) {
+    if constexpr (UnsatElementwise<N, OP>::value) {
+        // unsaturated multiplier (fp_unsat.cuh) when the multiplier operand is canonical; an
+        // operand >= p (outside the field, still defined for monty_mul) takes the saturated path,
+        // which forms the reference's integer T for every input
+        UParams<UF<N>::L> U;
+        uparams_from<N>(U, P);
+        if constexpr (OP == OP_TO_MONT) {
+            uint32_t c[N];
+            set_limbs<N>(c, P.r2);          // x may be any N-word value; R^2 mod p is canonical
+            umul_words<N>(r, x, c, U);
+        } else {
+            uint32_t d[N];
+            const bool canonical = sub_limbs_s<N>(d, OP == OP_MUL ? y : x, P.m) != 0;
+            if (canonical) {
+                if constexpr (OP == OP_MUL) umul_words<N>(r, x, y, U);
+                else usqr_words<N>(r, x, U);
+            } else {
+                if constexpr (OP == OP_MUL) mont_mul<N>(r, x, y, P);
+                else mont_sqr<N>(r, x, P);
+            }
+        }
+    } else if constexpr (OP == OP_MUL) mont_mul<N>(r, x, y, P);
+    else if constexpr (OP == OP_SQR) mont_sqr<N>(r, x, P);
+    else if constexpr (OP == OP_ADD) mod_add<N>(r, x, y, P);
+    else if constexpr (OP == OP_SUB) mod_sub<N>(r, x, y, P);
+    else if constexpr (OP == OP_NEG) mod_neg<N>(r, x, P);
+    else if constexpr (OP == OP_TO_MONT) mont_mul_const<N>(r, x, P.r2, P);
+    else if constexpr (OP == OP_FROM_MONT) mont_retrieve<N>(r, x, P);
+}
+
+// One element per lane per iteration, grid-stride.  (Two elements per lane with both loads issued up
+// front -- more bytes in flight per wave -- was measured and lost 1-4 % on every operation: the
+// million short-lived workgroups already keep the memory pipeline full.)
 template <int N, int OP>
 __global__ __launch_bounds__(kBlock) void k_elementwise(const uint32_t* __restrict__ a,
                                                         const uint32_t* __restrict__ b,
                                                         uint32_t* __restrict__ out, size_t n,
                                                         const FpParams<N> P) {
+    constexpr bool BIN = OP == OP_MUL || OP == OP_ADD || OP == OP_SUB;
     const size_t stride = (size_t)gridDim.x * kBlock;
     for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
         uint32_t x[N], y[N], r[N];
         load_elem<N>(x, a, i);
-        if constexpr (OP == OP_MUL || OP == OP_ADD || OP == OP_SUB) load_elem<N>(y, b, i);
-        if constexpr (UnsatElementwise<N, OP>::value) {
-            // unsaturated multiplier (fp_unsat.cuh) when the multiplier operand is canonical; an
-            // operand >= p (outside the field, still defined for monty_mul) takes the saturated path,
-            // which forms the reference's integer T for every input
-            UParams<UF<N>::L> U;
-            uparams_from<N>(U, P);
-            if constexpr (OP == OP_TO_MONT) {
-                set_limbs<N>(y, P.r2);          // x may be any N-word value; R^2 mod p is canonical
-                umul_words<N>(r, x, y, U);
-            } else {
-                uint32_t d[N];
-                const bool canonical = sub_limbs_s<N>(d, OP == OP_MUL ? y : x, P.m) != 0;
-                if (canonical) {
-                    if constexpr (OP == OP_MUL) umul_words<N>(r, x, y, U);
-                    else usqr_words<N>(r, x, U);
-                } else {
-                    if constexpr (OP == OP_MUL) mont_mul<N>(r, x, y, P);
-                    else mont_mul<N>(r, x, x, P);
-                }
-            }
-        } else if constexpr (OP == OP_MUL) mont_mul<N>(r, x, y, P);
-        else if constexpr (OP == OP_SQR) mont_mul<N>(r, x, x, P);
-        else if constexpr (OP == OP_ADD) mod_add<N>(r, x, y, P);
-        else if constexpr (OP == OP_SUB) mod_sub<N>(r, x, y, P);
-        else if constexpr (OP == OP_NEG) mod_neg<N>(r, x, P);
-        else if constexpr (OP == OP_TO_MONT) {
-            set_limbs<N>(y, P.r2);
-            mont_mul<N>(r, x, y, P);
-        } else if constexpr (OP == OP_FROM_MONT) mont_retrieve<N>(r, x, P);
+        if constexpr (BIN) load_elem<N>(y, b, i);
+        elementwise_op<N, OP>(r, x, BIN ? y : x, P);
         store_elem<N>(out, i, r);
     }
 }

@@ -353,7 +353,7 @@ struct Chain<N, false> {
     }
     __device__ __forceinline__ void square() {
         uint32_t t[N];
-        mont_mul<N>(t, v, v, P);
+        mont_sqr<N>(t, v, P);
         set(t);
     }
     // a multiplier used many times, prepared once
@@ -445,7 +445,7 @@ struct PowLadder<N, false> {
     }
     __device__ __forceinline__ void square() {
         uint32_t t[N];
-        mont_mul<N>(t, acc, acc, P);
+        mont_sqr<N>(t, acc, P);
 #pragma unroll
         for (int l = 0; l < N; l++) acc[l] = t[l];
     }
