@@ -325,12 +325,13 @@ def bench_matmul(args, world, rank, distributed, time_steps, primary, samples):
 
     steps = max(2, min(args.steps, 5)) if not primary else args.steps
     wall, kern = time_steps(step, steps, 1)
-    if rank == 0:   # three rows of C with their rows of A, and B, for the oracle in the CPU leg
+    if rank == 0:   # twelve entries of C with their rows of A and columns of B, for the oracle in the CPU leg
         torch.cuda.synchronize()
-        rs = [0, rows // 2 + 1, rows - 1]
+        rs, cs = [0, rows // 2 + 1, rows - 1], [0, 1, dim // 2 + 3, dim - 1]
+        Bm, Cm = B.view(dim, dim), C_local.view(rows, dim)
         samples["matmul"] = (np.stack([A[r * dim:(r + 1) * dim].cpu().numpy().view(np.uint64).reshape(-1) for r in rs]),
-                             B.cpu().numpy().view(np.uint64).reshape(-1),
-                             np.stack([C_local[r * dim:(r + 1) * dim].cpu().numpy().view(np.uint64).reshape(-1) for r in rs]), dim)
+                             np.stack([Bm[:, c].contiguous().cpu().numpy().view(np.uint64).reshape(-1) for c in cs]),
+                             np.array([[int(Cm[r, c].item()) & 0xFFFFFFFFFFFFFFFF for c in cs] for r in rs], dtype=np.uint64), dim)
     gathered_ms = None
     if distributed:
         wall_g, _ = time_steps(step_gathered, max(2, min(steps, 5)), 1)
@@ -493,10 +494,10 @@ def cpu_baseline(sample=None, samples=None):
             checks[name] = all(np.array_equal(o.matvec(rowsA[i], 1, dim, x, threads=0).reshape(-1), y[i].reshape(-1))
                                for i in range(len(rowsA)))
         elif name == "matmul":
-            rowsA, B, rowsC, dim = smp
+            rowsA, colsB, entries, dim = smp    # C[r][c] = sum_l mul(A[r][l], B[l][c]): the fold of mul then add
             og = Oracle(cpa.GOLDILOCKS, 1)
-            checks[name] = all(np.array_equal(og.matmul(rowsA[i].reshape(-1, 1), B.reshape(-1, 1), 1, dim, dim, threads=0).reshape(-1),
-                                              rowsC[i].reshape(-1)) for i in range(len(rowsA)))
+            checks[name] = all(int(og.sum(og.mul(rowsA[i].reshape(-1, 1), colsB[j].reshape(-1, 1)))[0]) == int(entries[i, j])
+                               for i in range(len(rowsA)) for j in range(len(colsB)))
         elif name == "batch_inv":
             xs, inv = smp
             oq = Oracle(cpa.BLS12_381_FQ, 6)
