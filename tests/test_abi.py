@@ -165,3 +165,27 @@ def test_spmv_argument_checks_need_no_gpu():
     assert b"column index" in lib.fpgpu_last_error_string()
     assert lib.fpgpu_spmv(f._h, None, None, 0, 3, 2, None, None) == _lib.OK          # no rows: nothing to do
     assert lib.fpgpu_spmv_dev(f._h, None, None, 4, 3, 2, None, None, None) == _lib.ERR_SHAPE
+
+
+def test_handle_api_argument_checks_need_no_gpu():
+    """fpgpu_vec_* / fpgpu_set_devices: null handles and bad lists are reported through status codes;
+    without a GPU an allocation is FPGPU_ERR_NO_DEVICE (no CPU fallback); clearing the list is always allowed."""
+    lib = cpa.load()
+    f = cpa.MontyField(cpa.BN254_FR, 4)
+    assert lib.fpgpu_set_devices(None, 0) == _lib.OK
+    assert lib.fpgpu_get_devices(None, 0) == 0
+    assert lib.fpgpu_set_devices(None, 3) == _lib.ERR_SHAPE
+    assert lib.fpgpu_vec_len(None) == 0 and lib.fpgpu_vec_parts(None) == 0
+    lib.fpgpu_vec_free(None)
+    assert lib.fpgpu_vec_mul(f._h, None, None, None) == _lib.ERR_SHAPE
+    assert lib.fpgpu_vec_sync(None) == _lib.ERR_SHAPE
+    assert lib.fpgpu_vec_upload(None, None, 0, 0) == _lib.ERR_SHAPE
+    h = ctypes.c_void_p()
+    rc = lib.fpgpu_vec_alloc(f._h, 16, _lib.PLACE_CURRENT, ctypes.byref(h))
+    if lib.fpgpu_device_count() == 0:
+        assert rc == _lib.ERR_NO_DEVICE and not h.value
+    else:
+        assert rc == _lib.OK
+        lib.fpgpu_vec_free(h)
+    assert lib.fpgpu_vec_alloc(f._h, 16, -77, ctypes.byref(h)) in (_lib.ERR_SHAPE, _lib.ERR_NO_DEVICE)
+    assert lib.fpgpu_dot(f._h, None, None, 0, None) == _lib.ERR_SHAPE          # out is required even for n = 0

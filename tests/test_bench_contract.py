@@ -1,13 +1,22 @@
-"""CPU: the committed bench line (profiles/r1_bench_latest.json, written by bench.py on an MI355X)
-carries every field of the driver's contract, with consistent arithmetic."""
+"""CPU: the committed bench line (profiles/r<NN>_bench_latest.json of the newest round, written by bench.py
+on an MI355X) carries every field of the driver's contract, with consistent arithmetic; and the PMC
+traffic it quotes comes from a pass taken on the kernel sources that are in the tree."""
+import glob
 import json
 import os
+import sys
 
 from conftest import ROOT
 
+sys.path.insert(0, ROOT)
+
+
+def _latest(name):
+    return sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_" + name)))[-1]
+
 
 def test_recorded_bench_line_has_the_contract_fields():
-    line = open(os.path.join(ROOT, "profiles", "r1_bench_latest.json")).read().strip().splitlines()[-1]
+    line = open(_latest("bench_latest.json")).read().strip().splitlines()[-1]
     d = json.loads(line)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
@@ -18,6 +27,7 @@ def test_recorded_bench_line_has_the_contract_fields():
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r, k
     assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert "traffic_source" in r                      # where the PMC figure comes from, or why there is none
     # achieved = algorithmic bytes per launch / measured launch duration
     assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e9) < 1e-3 * r["achieved"]
     # PMC traffic is per launch and close to the algorithmic bytes for this streaming kernel
@@ -29,3 +39,28 @@ def test_recorded_bench_line_has_the_contract_fields():
     # value = elements of all ranks / wall time, consistent with ms_per_step
     per_step = d["config"]["elements_per_gpu"] * d["n_gpus"]
     assert abs(d["value"] - per_step / (d["ms_per_step"] * 1e-3) / 1e9) < 1e-6 * d["value"]
+
+
+def test_batch_inversion_is_reported_against_the_valu_roofline():
+    d = json.loads(open(_latest("bench_latest.json")).read().strip().splitlines()[-1])
+    inv = d["extra"]["batch_inv_bls12_381"]
+    assert inv["bound"] == "valu" and inv["mads_per_element"] == 900
+    assert abs(inv["valu_frac"] - inv["valu_mad_Tops_per_gpu"] / 39.3) < 1e-6
+    assert "valu_kernel_ms_for_comparison" not in d["extra"]["matmul_goldilocks"]      # timed live now
+    assert d["extra"]["matmul_goldilocks"]["valu_kernel_ms_same_run"] > 50
+    assert "inferred" in d["extra"]["matmul_goldilocks"]["int8_peak_note"]
+
+
+def test_stored_pmc_traffic_matches_the_kernel_sources_in_the_tree():
+    """bench.py quotes profiles/r*_pmc_traffic_*.json only when the pass measured the kernel sources that
+    are in the tree now; the newest round's files must therefore carry the current digest."""
+    from bench import _pmc_traffic, kernel_sources_sha256
+    sha = kernel_sources_sha256()
+    for w, key, val in (("mul", "elements", 1 << 28), ("matvec", "rows", 1 << 15), ("matmul", "dim", 8192),
+                        ("batch_inv", "elements", 1 << 24)):
+        pmc = json.load(open(_latest("pmc_traffic_%s.json" % w)))
+        assert pmc["kernel_sources_sha256"] == sha, "re-run tools/collect_r2.sh + tools/summarise_r2.py after kernel changes (%s)" % w
+        traffic, src = _pmc_traffic(w, key, val)
+        assert traffic and traffic >= 0.99 * pmc["algorithmic_bytes_per_launch"] and "same kernel sources" in src
+    # a stale or mismatched pass yields no figure
+    assert _pmc_traffic("mul", "elements", 12345)[0] is None
