@@ -209,6 +209,8 @@ def main():
         if args.workload != "matvec":
             extra["matvec_bn254"] = bench_matvec(args, f, world, rank, distributed, time_steps, False, samples)
         extra["spmv_bn254"] = bench_spmv(f, rank, time_steps)
+        if rank == 0:
+            extra["drop_in_chain_bn254"] = bench_drop_in_chain(f)
 
     # ---------------- CPU baseline (rank 0, N = 1 only) --------------------------------
     cpu = None
@@ -432,6 +434,60 @@ def bench_spmv(f, rank, time_steps):
     bytes_alg = 36.0 * rows * density + 32.0 * (cols + rows)   # value + index per cell, x and y once
     return {"cells_per_s": rows * density / kern, "ms": kern * 1e3, "rows": rows, "density": density,
             "hbm_GBps_per_gpu": bytes_alg / kern / 1e9, "hbm_frac": bytes_alg / kern / 1e9 / HBM_PEAK_GBPS}
+
+
+def bench_drop_in_chain(f):
+    """What the boundary costs a host caller that chains operations (t = a*b; u = t + a; v = u^2 over 2^22 BN254
+    elements, host arrays in, host array out): the host-buffer calls move every operand of every call over
+    PCIe (5 uploads, 3 downloads); the handle API uploads a and b once, keeps t and u in HBM and downloads v
+    once; the third line is the same chain on vectors that are already resident (no PCIe at all)."""
+    import numpy as np
+    import crypto_primitives_amd as cpa
+    n = 1 << 22
+    rng = np.random.default_rng(5)
+    ha = rng.integers(0, 1 << 62, size=(n, 4), dtype=np.uint64)
+    hb = rng.integers(0, 1 << 62, size=(n, 4), dtype=np.uint64)
+    ha[:, 3] &= (1 << 60) - 1
+    hb[:, 3] &= (1 << 60) - 1
+
+    def host_calls():
+        return f.sqr(f.add(f.mul(ha, hb), ha))
+
+    V = cpa.DeviceVector
+    vt, vu, vv = V.alloc(f, n), V.alloc(f, n), V.alloc(f, n)
+    va, vb = V.alloc(f, n), V.alloc(f, n)
+
+    def handles():
+        va.upload(ha)
+        vb.upload(hb)
+        f.mul_vec(va, vb, vt)
+        f.add_vec(vt, va, vu)
+        f.sqr_vec(vu, vv)
+        return vv.download()
+
+    def resident():
+        f.mul_vec(va, vb, vt)
+        f.add_vec(vt, va, vu)
+        f.sqr_vec(vu, vv)
+        vv.sync()
+
+    out = {}
+    ref = None
+    for name, fn, reps in (("host_buffer_calls", host_calls, 3), ("handles_upload_chain_download", handles, 3),
+                           ("handles_resident", resident, 20)):
+        r = fn()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            r = fn()
+        dt = (time.perf_counter() - t0) / reps
+        out[name] = {"ms": dt * 1e3, "Gelem_per_s": n / dt / 1e9}
+        if r is not None:
+            same = True if ref is None else bool(np.array_equal(r, ref))
+            ref = r if ref is None else ref
+            out[name]["same_result"] = same
+    out["elements"] = n
+    out["ops"] = "t = a*b; u = t + a; v = u^2"
+    return out
 
 
 def _latest_profile(name):

@@ -173,6 +173,8 @@ void destroy_comms() {
     if (!g_comm_ready) return;
     for (Slot* s : g_list)
         if (s->comm) {
+            // collectives still queued on this entry's stream must be through before their communicator goes
+            if (hipSetDevice(s->device) == hipSuccess) (void)hipStreamSynchronize(s->stream);
             (void)g_rccl.CommDestroy(s->comm);
             s->comm = nullptr;
         }
