@@ -503,8 +503,9 @@ def kernel_sources_sha256():
     import glob
     import hashlib
     h = hashlib.sha256()
+    host_only = ("fpgpu_vec.hip", "fpgpu_stage.hip", "fpgpu_internal.hpp")   # handles, copies: no kernel, no launch geometry
     for path in sorted(glob.glob(os.path.join(ROOT, "crypto_primitives_amd", "csrc", "*"))):
-        if path.endswith((".cuh", ".hip", ".hpp", ".inc")):
+        if path.endswith((".cuh", ".hip", ".hpp", ".inc")) and os.path.basename(path) not in host_only:
             h.update(os.path.basename(path).encode())
             h.update(open(path, "rb").read())
     return h.hexdigest()

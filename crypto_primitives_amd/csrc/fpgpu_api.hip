@@ -108,7 +108,7 @@ static const TuningEntry kTuningEntries[] = {
     {"FPGPU_MATVEC_MFMA", &Tuning::matvec_mfma},   {"FPGPU_MATVEC_KSPLIT", &Tuning::matvec_ksplit},
     {"FPGPU_MATVEC_T", &Tuning::matvec_t},         {"FPGPU_MATMUL_MFMA", &Tuning::matmul_mfma},
     {"FPGPU_MATMUL_GENERIC", &Tuning::matmul_generic}, {"FPGPU_SPMV_LOG2G", &Tuning::spmv_log2g},
-    {"FPGPU_ALLGATHER_COPY", &Tuning::allgather_copy},
+    {"FPGPU_ALLGATHER_COPY", &Tuning::allgather_copy}, {"FPGPU_COPY_THREADS", &Tuning::copy_threads},
 };
 static Tuning g_tuning_defaults;
 static Tuning g_tuning;
@@ -219,11 +219,11 @@ int host_binary(const fpgpu_ctx* ctx, const uint64_t* a, const uint64_t* b, uint
     CHECK(da.alloc(bytes));
     if (has_b) CHECK(db.alloc(bytes));
     CHECK(dout.alloc(bytes));
-    HIP_TRY(hipMemcpy(da.p, a, bytes, hipMemcpyHostToDevice));
-    if (has_b) HIP_TRY(hipMemcpy(db.p, b, bytes, hipMemcpyHostToDevice));
+    CHECK(upload_staged(da.p, a, bytes, nullptr));
+    if (has_b) CHECK(upload_staged(db.p, b, bytes, nullptr));
     CHECK(dev_call(da.p, db.p, dout.p));
     HIP_TRY(hipStreamSynchronize(nullptr));
-    HIP_TRY(hipMemcpy(out, dout.p, bytes, hipMemcpyDeviceToHost));
+    CHECK(download_staged(out, dout.p, bytes, nullptr));
     return FPGPU_OK;
 }
 
@@ -554,10 +554,10 @@ static int fold_host(bool product, const fpgpu_ctx* ctx, const uint64_t* v, size
     CHECK(dv.alloc(n * esz));
     CHECK(dout.alloc(esz));
     CHECK(ws.alloc(fpgpu_fold_workspace_bytes(ctx)));
-    if (n) HIP_TRY(hipMemcpy(dv.p, v, n * esz, hipMemcpyHostToDevice));
+    if (n) CHECK(upload_staged(dv.p, v, n * esz, nullptr));
     CHECK(fold_dev(product, ctx, dv.p, n, dout.p, ws.p, fpgpu_fold_workspace_bytes(ctx), nullptr));
     HIP_TRY(hipStreamSynchronize(nullptr));
-    HIP_TRY(hipMemcpy(out, dout.p, esz, hipMemcpyDeviceToHost));
+    CHECK(download_staged(out, dout.p, esz, nullptr));
     return FPGPU_OK;
 }
 int fpgpu_sum(const fpgpu_ctx* ctx, const uint64_t* v, size_t n, uint64_t* out) { return fold_host(false, ctx, v, n, out); }
@@ -576,12 +576,12 @@ int fpgpu_dot(const fpgpu_ctx* ctx, const uint64_t* a, const uint64_t* b, size_t
     CHECK(dout.alloc(esz));
     CHECK(ws.alloc(fpgpu_fold_workspace_bytes(ctx)));
     if (n) {
-        HIP_TRY(hipMemcpy(da.p, a, n * esz, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(db.p, b, n * esz, hipMemcpyHostToDevice));
+        CHECK(upload_staged(da.p, a, n * esz, nullptr));
+        CHECK(upload_staged(db.p, b, n * esz, nullptr));
     }
     CHECK(fpgpu_dot_dev(ctx, da.p, db.p, n, dout.p, ws.p, fpgpu_fold_workspace_bytes(ctx), nullptr));
     HIP_TRY(hipStreamSynchronize(nullptr));
-    HIP_TRY(hipMemcpy(out, dout.p, esz, hipMemcpyDeviceToHost));
+    CHECK(download_staged(out, dout.p, esz, nullptr));
     return FPGPU_OK;
 }
 
@@ -597,11 +597,11 @@ int fpgpu_batch_inv(const fpgpu_ctx* ctx, const uint64_t* x, uint64_t* out, uint
     CHECK(dout.alloc(bytes));
     CHECK(dflags.alloc(n));
     CHECK(ws.alloc(wsb));
-    HIP_TRY(hipMemcpy(dx.p, x, bytes, hipMemcpyHostToDevice));
+    CHECK(upload_staged(dx.p, x, bytes, nullptr));
     CHECK(fpgpu_batch_inv_dev(ctx, dx.p, dout.p, (uint8_t*)dflags.p, n, ws.p, wsb, nullptr));
     HIP_TRY(hipStreamSynchronize(nullptr));
-    HIP_TRY(hipMemcpy(out, dout.p, bytes, hipMemcpyDeviceToHost));
-    if (zero_flags) HIP_TRY(hipMemcpy(zero_flags, dflags.p, n, hipMemcpyDeviceToHost));
+    CHECK(download_staged(out, dout.p, bytes, nullptr));
+    if (zero_flags) CHECK(download_staged(zero_flags, dflags.p, n, nullptr));
     return FPGPU_OK;
 }
 
@@ -616,15 +616,15 @@ int fpgpu_matvec(const fpgpu_ctx* ctx, const uint64_t* A, size_t rows, size_t co
     CHECK(dx.alloc(cols * esz));
     CHECK(dy.alloc(rows * esz));
     if (cols) {
-        HIP_TRY(hipMemcpy(dA.p, A, rows * cols * esz, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(dx.p, x, cols * esz, hipMemcpyHostToDevice));
+        CHECK(upload_staged(dA.p, A, rows * cols * esz, nullptr));
+        CHECK(upload_staged(dx.p, x, cols * esz, nullptr));
     }
     DevBuf ws;
     const size_t ws_bytes = fpgpu_matvec_workspace_bytes(ctx, rows, cols);
     if (ws_bytes) CHECK(ws.alloc(ws_bytes));
     CHECK(fpgpu_matvec_dev(ctx, dA.p, rows, cols, dx.p, dy.p, ws_bytes ? ws.p : nullptr, ws_bytes, nullptr));
     HIP_TRY(hipStreamSynchronize(nullptr));
-    HIP_TRY(hipMemcpy(y, dy.p, rows * esz, hipMemcpyDeviceToHost));
+    CHECK(download_staged(y, dy.p, rows * esz, nullptr));
     return FPGPU_OK;
 }
 
@@ -645,13 +645,13 @@ int fpgpu_spmv(const fpgpu_ctx* ctx, const uint64_t* vals, const uint32_t* col_i
     CHECK(dx.alloc(cols * esz));
     CHECK(dy.alloc(rows * esz));
     if (cells) {
-        HIP_TRY(hipMemcpy(dv.p, vals, cells * esz, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(dc.p, col_idx, cells * 4, hipMemcpyHostToDevice));
+        CHECK(upload_staged(dv.p, vals, cells * esz, nullptr));
+        CHECK(upload_staged(dc.p, col_idx, cells * 4, nullptr));
     }
-    if (cols) HIP_TRY(hipMemcpy(dx.p, x, cols * esz, hipMemcpyHostToDevice));
+    if (cols) CHECK(upload_staged(dx.p, x, cols * esz, nullptr));
     CHECK(fpgpu_spmv_dev(ctx, dv.p, (const uint32_t*)dc.p, rows, cols, density, dx.p, dy.p, nullptr));
     HIP_TRY(hipStreamSynchronize(nullptr));
-    HIP_TRY(hipMemcpy(y, dy.p, rows * esz, hipMemcpyDeviceToHost));
+    CHECK(download_staged(y, dy.p, rows * esz, nullptr));
     return FPGPU_OK;
 }
 
@@ -667,15 +667,15 @@ int fpgpu_matmul(const fpgpu_ctx* ctx, const uint64_t* A, const uint64_t* B, uin
     CHECK(dB.alloc(k * n * esz));
     CHECK(dC.alloc(m * n * esz));
     if (k) {
-        HIP_TRY(hipMemcpy(dA.p, A, m * k * esz, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(dB.p, B, k * n * esz, hipMemcpyHostToDevice));
+        CHECK(upload_staged(dA.p, A, m * k * esz, nullptr));
+        CHECK(upload_staged(dB.p, B, k * n * esz, nullptr));
     }
     DevBuf ws;
     const size_t ws_bytes = fpgpu_matmul_workspace_bytes(ctx, m, k, n);
     if (ws_bytes) CHECK(ws.alloc(ws_bytes));
     CHECK(fpgpu_matmul_dev(ctx, dA.p, dB.p, dC.p, m, k, n, ws_bytes ? ws.p : nullptr, ws_bytes, nullptr));
     HIP_TRY(hipStreamSynchronize(nullptr));
-    HIP_TRY(hipMemcpy(C, dC.p, m * n * esz, hipMemcpyDeviceToHost));
+    CHECK(download_staged(C, dC.p, m * n * esz, nullptr));
     return FPGPU_OK;
 }
 

@@ -14,6 +14,11 @@ extern thread_local std::string g_last_error;
 int fail(int code, const std::string& msg);       // records msg for fpgpu_last_error_string(), returns code
 int hip_fail(hipError_t e, const char* what);     // FPGPU_ERR_HIP with the runtime's message
 
+// Host <-> device copies through the library's pinned staging buffers and copy threads
+// (fpgpu_stage.hip); both return when the host buffer is the caller's again / holds the data.
+int upload_staged(void* dev, const void* host, size_t bytes, hipStream_t stream);
+int download_staged(void* host, const void* dev, size_t bytes, hipStream_t stream);
+
 }  // namespace fpgpu
 
 #define HIP_TRY(expr)                                            \

@@ -571,12 +571,9 @@ int fpgpu_vec_upload(fpgpu_vec* v, const uint64_t* host, size_t first, size_t n)
         const size_t lo = std::max(first, p.first), hi = std::min(first + n, p.first + p.count);
         if (lo >= hi) continue;
         HIP_TRY(hipSetDevice(p.slot->device));
-        HIP_TRY(hipMemcpyAsync(p.ptr + (lo - p.first) * esz, host + (lo - first) * v->n64, (hi - lo) * esz,
-                               hipMemcpyHostToDevice, p.slot->stream));
-    }
-    for (VecPart& p : v->parts) {  // the host buffer is the caller's again when this returns
-        HIP_TRY(hipSetDevice(p.slot->device));
-        HIP_TRY(hipStreamSynchronize(p.slot->stream));
+        // (returns when the host range has been read; the last chunks may still be in flight on the
+        // part's stream, which orders every later operation on this vector behind them)
+        CHECK(upload_staged(p.ptr + (lo - p.first) * esz, host + (lo - first) * v->n64, (hi - lo) * esz, p.slot->stream));
     }
     return FPGPU_OK;
 }
@@ -594,12 +591,7 @@ int fpgpu_vec_download(const fpgpu_vec* v, uint64_t* host, size_t first, size_t 
         const size_t lo = std::max(first, p.first), hi = std::min(first + n, p.first + p.count);
         if (lo >= hi) continue;
         HIP_TRY(hipSetDevice(p.slot->device));
-        HIP_TRY(hipMemcpyAsync(host + (lo - first) * v->n64, p.ptr + (lo - p.first) * esz, (hi - lo) * esz,
-                               hipMemcpyDeviceToHost, p.slot->stream));
-    }
-    for (size_t pi = 0; pi < nparts; pi++) {
-        HIP_TRY(hipSetDevice(v->parts[pi].slot->device));
-        HIP_TRY(hipStreamSynchronize(v->parts[pi].slot->stream));
+        CHECK(download_staged(host + (lo - first) * v->n64, p.ptr + (lo - p.first) * esz, (hi - lo) * esz, p.slot->stream));
     }
     return FPGPU_OK;
 }

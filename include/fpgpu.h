@@ -30,7 +30,9 @@
  * call is asynchronous on `stream` (a hipStream_t, NULL = default stream) of the
  * current HIP device and allocates nothing.  The host-buffer calls are
  * synchronous, run on the current device, and stage through device memory they
- * allocate and free themselves.
+ * allocate and free themselves; their host <-> device copies go through pinned
+ * staging buffers of the library, filled and drained by a few host threads
+ * (pageable caller memory cannot be pinned in place).
  */
 #ifndef FPGPU_H
 #define FPGPU_H
@@ -297,7 +299,7 @@ int fpgpu_vec_matmul(const fpgpu_ctx *ctx, const fpgpu_vec *A, const fpgpu_vec *
 /* ---- tuning / test hooks -----------------------------------------------------
  * No counterpart in the reference.  The hooks of INTEGRATION.md section 4 (FPGPU_GRID_CAP,
  * FPGPU_INV_C, FPGPU_MATVEC_MFMA, FPGPU_MATVEC_KSPLIT, FPGPU_MATVEC_T, FPGPU_MATMUL_MFMA,
- * FPGPU_MATMUL_GENERIC, FPGPU_SPMV_LOG2G, FPGPU_ALLGATHER_COPY) are read from the environment once, when the library
+ * FPGPU_MATMUL_GENERIC, FPGPU_SPMV_LOG2G, FPGPU_ALLGATHER_COPY, FPGPU_COPY_THREADS) are read from the environment once, when the library
  * is first used; this call sets one afterwards (process-wide; FPGPU_TUNING_DEFAULT restores the
  * library's choice).  No hook changes a result -- they pick between bit-identical paths.  Not
  * synchronised against calls running on other threads. */

@@ -18,6 +18,7 @@ for n in 2 4 6 8 10 12 14 16; do
 done
 hipcc $HF $FLAGS -c -o ../build/obj/fpgpu_api_$NAME.o csrc/fpgpu_api.hip &
 hipcc $HF $FLAGS -c -o ../build/obj/fpgpu_vec_$NAME.o csrc/fpgpu_vec.hip &
+hipcc $HF $FLAGS -c -o ../build/obj/fpgpu_stage_$NAME.o csrc/fpgpu_stage.hip &
 wait
-hipcc --offload-arch=gfx950 -shared -fPIC -o ../build/libfpgpu_$NAME.so ../build/obj/fpgpu_api_$NAME.o ../build/obj/fpgpu_vec_$NAME.o $OBJS -ldl
+hipcc --offload-arch=gfx950 -shared -fPIC -o ../build/libfpgpu_$NAME.so ../build/obj/fpgpu_api_$NAME.o ../build/obj/fpgpu_vec_$NAME.o ../build/obj/fpgpu_stage_$NAME.o $OBJS -ldl -lpthread
 echo built build/libfpgpu_$NAME.so
