@@ -51,16 +51,29 @@ def test_batch_inversion_is_reported_against_the_valu_roofline():
     assert "inferred" in d["extra"]["matmul_goldilocks"]["int8_peak_note"]
 
 
-def test_stored_pmc_traffic_matches_the_kernel_sources_in_the_tree():
+def test_pmc_traffic_is_quoted_only_from_a_pass_on_the_same_kernel_sources(tmp_path, monkeypatch):
     """bench.py quotes profiles/r*_pmc_traffic_*.json only when the pass measured the kernel sources that
-    are in the tree now; the newest round's files must therefore carry the current digest."""
-    from bench import _pmc_traffic, kernel_sources_sha256
-    sha = kernel_sources_sha256()
+    are in the tree now (each file carries their SHA-256): a fresh file gives the figure and names its
+    commit, a stale one gives None and says so, a pass over another problem size gives None."""
+    import bench
+    sha = bench.kernel_sources_sha256()
     for w, key, val in (("mul", "elements", 1 << 28), ("matvec", "rows", 1 << 15), ("matmul", "dim", 8192),
                         ("batch_inv", "elements", 1 << 24)):
         pmc = json.load(open(_latest("pmc_traffic_%s.json" % w)))
-        assert pmc["kernel_sources_sha256"] == sha, "re-run tools/collect_r2.sh + tools/summarise_r2.py after kernel changes (%s)" % w
-        traffic, src = _pmc_traffic(w, key, val)
-        assert traffic and traffic >= 0.99 * pmc["algorithmic_bytes_per_launch"] and "same kernel sources" in src
-    # a stale or mismatched pass yields no figure
-    assert _pmc_traffic("mul", "elements", 12345)[0] is None
+        traffic, src = bench._pmc_traffic(w, key, val)
+        if pmc["kernel_sources_sha256"] == sha:
+            assert traffic and traffic >= 0.99 * pmc["algorithmic_bytes_per_launch"] and "same kernel sources" in src
+        else:   # collected before the last kernel change: must not be quoted
+            assert traffic is None and "stale" in src
+        assert bench._pmc_traffic(w, key, 12345)[0] is None
+    # the same logic on a synthetic pair of files, so that both branches are always exercised
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    (tmp_path / "profiles").mkdir()
+    (tmp_path / "crypto_primitives_amd" / "csrc").mkdir(parents=True)
+    (tmp_path / "crypto_primitives_amd" / "csrc" / "k.cuh").write_text("kernel v1")
+    fresh = {"elements": 8, "traffic_bytes_per_launch": 777.0, "commit": "abc1234", "kernel_sources_sha256": bench.kernel_sources_sha256()}
+    (tmp_path / "profiles" / "r9_pmc_traffic_mul.json").write_text(json.dumps(fresh))
+    assert bench._pmc_traffic("mul", "elements", 8) == (777.0, "profiles/r9_pmc_traffic_mul.json (collected at commit abc1234, same kernel sources as this tree)")
+    (tmp_path / "crypto_primitives_amd" / "csrc" / "k.cuh").write_text("kernel v2")
+    t, src = bench._pmc_traffic("mul", "elements", 8)
+    assert t is None and "stale" in src and "abc1234" in src
