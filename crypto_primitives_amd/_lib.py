@@ -90,6 +90,10 @@ SIGNATURES = {
     "fpgpu_vec_dot": (_int, [_vp, _vp, _vp, _vp]),
     "fpgpu_vec_matvec": (_int, [_vp, _vp, _sz, _sz, _vp, _vp]),
     "fpgpu_vec_matmul": (_int, [_vp, _vp, _vp, _vp, _sz, _sz, _sz]),
+    "fpgpu_idx_alloc_rows": (_int, [_sz, _sz, _int, _c.POINTER(_vp)]),
+    "fpgpu_idx_free": (None, [_vp]),
+    "fpgpu_idx_upload": (_int, [_vp, _vp, _sz, _sz]),
+    "fpgpu_vec_spmv": (_int, [_vp, _vp, _vp, _sz, _sz, _sz, _vp, _vp]),
     "fpgpu_tuning_set": (_int, [_c.c_char_p, _c.c_long]),
     "fpgpu_last_error_string": (_c.c_char_p, []),
     "fpgpu_device_count": (_int, []),

@@ -22,6 +22,7 @@
 #include <cstring>
 #include <memory>
 #include <mutex>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -203,11 +204,15 @@ struct VecPart {
     char* ptr;            // device memory of this part (the whole vector for a replica)
 };
 struct fpgpu_vec {
-    uint32_t n64 = 0;
+    uint32_t n64 = 0;      // words per element; 0 for a vector of 32-bit indices (fpgpu_idx)
     size_t n = 0;
     int kind = VEC_SINGLE;
     std::vector<VecPart> parts;
-    size_t esz() const { return (size_t)n64 * 8; }
+    size_t esz() const { return n64 ? (size_t)n64 * 8 : 4; }
+};
+// Column indices of a SparseMatrix: the same container with 4-byte elements.
+struct fpgpu_idx {
+    fpgpu_vec v;
 };
 
 namespace {
@@ -219,8 +224,13 @@ int check_vec(const fpgpu_ctx* ctx, const fpgpu_vec* v, const char* name) {
     return FPGPU_OK;
 }
 
+int vec_alloc_n64(uint32_t n64, size_t n, size_t unit, int placement, fpgpu_vec** out);
 int vec_alloc(const fpgpu_ctx* ctx, size_t n, size_t unit, int placement, fpgpu_vec** out) {
     if (!ctx || !out) return fail(FPGPU_ERR_SHAPE, "null pointer");
+    return vec_alloc_n64(ctx->n64, n, unit, placement, out);
+}
+int vec_alloc_n64(uint32_t n64, size_t n, size_t unit, int placement, fpgpu_vec** out) {
+    if (!out) return fail(FPGPU_ERR_SHAPE, "null pointer");
     *out = nullptr;
     if (n > ((size_t)1 << 40)) return fail(FPGPU_ERR_SHAPE, "element count too large");
     if (unit == 0) unit = 1;
@@ -230,7 +240,7 @@ int vec_alloc(const fpgpu_ctx* ctx, size_t n, size_t unit, int placement, fpgpu_
     CHECK(device_count(&ndev));
     DeviceGuard guard;
     auto v = std::make_unique<fpgpu_vec>();
-    v->n64 = ctx->n64;
+    v->n64 = n64;
     v->n = n;
     if (placement >= 0 || placement == FPGPU_PLACE_CURRENT) {
         int dev = placement;
@@ -559,7 +569,12 @@ int fpgpu_vec_part(const fpgpu_vec* v, int i, int* device, size_t* first, size_t
     return FPGPU_OK;
 }
 
+static int vec_upload_bytes(fpgpu_vec* v, const char* host, size_t first, size_t n);
 int fpgpu_vec_upload(fpgpu_vec* v, const uint64_t* host, size_t first, size_t n) {
+    if (v && v->n64 == 0) return fail(FPGPU_ERR_SHAPE, "vec_upload: not a vector of field elements");
+    return vec_upload_bytes(v, (const char*)host, first, n);
+}
+static int vec_upload_bytes(fpgpu_vec* v, const char* host, size_t first, size_t n) {
     if (!v) return fail(FPGPU_ERR_SHAPE, "null vector");
     if (first > v->n || n > v->n - first) return fail(FPGPU_ERR_SHAPE, "vec_upload: range beyond the vector");
     if (n == 0) return FPGPU_OK;
@@ -573,12 +588,17 @@ int fpgpu_vec_upload(fpgpu_vec* v, const uint64_t* host, size_t first, size_t n)
         HIP_TRY(hipSetDevice(p.slot->device));
         // (returns when the host range has been read; the last chunks may still be in flight on the
         // part's stream, which orders every later operation on this vector behind them)
-        CHECK(upload_staged(p.ptr + (lo - p.first) * esz, host + (lo - first) * v->n64, (hi - lo) * esz, p.slot->stream));
+        CHECK(upload_staged(p.ptr + (lo - p.first) * esz, host + (lo - first) * esz, (hi - lo) * esz, p.slot->stream));
     }
     return FPGPU_OK;
 }
 
+static int vec_download_bytes(const fpgpu_vec* v, char* host, size_t first, size_t n);
 int fpgpu_vec_download(const fpgpu_vec* v, uint64_t* host, size_t first, size_t n) {
+    if (v && v->n64 == 0) return fail(FPGPU_ERR_SHAPE, "vec_download: not a vector of field elements");
+    return vec_download_bytes(v, (char*)host, first, n);
+}
+static int vec_download_bytes(const fpgpu_vec* v, char* host, size_t first, size_t n) {
     if (!v) return fail(FPGPU_ERR_SHAPE, "null vector");
     if (first > v->n || n > v->n - first) return fail(FPGPU_ERR_SHAPE, "vec_download: range beyond the vector");
     if (n == 0) return FPGPU_OK;
@@ -591,7 +611,7 @@ int fpgpu_vec_download(const fpgpu_vec* v, uint64_t* host, size_t first, size_t 
         const size_t lo = std::max(first, p.first), hi = std::min(first + n, p.first + p.count);
         if (lo >= hi) continue;
         HIP_TRY(hipSetDevice(p.slot->device));
-        CHECK(download_staged(host + (lo - first) * v->n64, p.ptr + (lo - p.first) * esz, (hi - lo) * esz, p.slot->stream));
+        CHECK(download_staged(host + (lo - first) * esz, p.ptr + (lo - p.first) * esz, (hi - lo) * esz, p.slot->stream));
     }
     return FPGPU_OK;
 }
@@ -819,6 +839,55 @@ int fpgpu_vec_matmul(const fpgpu_ctx* ctx, const fpgpu_vec* A, const fpgpu_vec* 
         const size_t wsb = fpgpu_matmul_workspace_bytes(ctx, prows, k, n);
         if (wsb) CHECK(ensure_scratch(a.slot, wsb));
         return fpgpu_matmul_dev(ctx, a.ptr, pb, dst, prows, k, n, wsb ? a.slot->scratch : nullptr, wsb, a.slot->stream);
+    });
+}
+
+// ---- sparse mat-vec over SparseMatrix<T> (src/matrix.rs:46-61) on handles ------------------------------
+// The cells' two halves live in two containers with the same row partition: `vals` (rows * density
+// elements, fpgpu_vec_alloc_rows(rows, density)) and `col_idx` (rows * density 32-bit column indices).
+int fpgpu_idx_alloc_rows(size_t rows, size_t density, int placement, fpgpu_idx** out) {
+    if (!out) return fail(FPGPU_ERR_SHAPE, "null pointer");
+    *out = nullptr;
+    if (density && rows > ((size_t)1 << 40) / density) return fail(FPGPU_ERR_SHAPE, "sparse matrix too large");
+    fpgpu_vec* v = nullptr;
+    CHECK(vec_alloc_n64(0, rows * density, density, placement, &v));
+    auto idx = new (std::nothrow) fpgpu_idx();
+    if (!idx) {
+        fpgpu_vec_free(v);
+        return fail(FPGPU_ERR_HIP, "out of host memory");
+    }
+    idx->v = std::move(*v);   // the parts (device memory) move into the index container
+    delete v;
+    *out = idx;
+    return FPGPU_OK;
+}
+void fpgpu_idx_free(fpgpu_idx* idx) {
+    if (!idx) return;
+    auto v = new fpgpu_vec(std::move(idx->v));
+    delete idx;
+    fpgpu_vec_free(v);
+}
+int fpgpu_idx_upload(fpgpu_idx* idx, const uint32_t* host, size_t first, size_t n) {
+    if (!idx) return fail(FPGPU_ERR_SHAPE, "null index vector");
+    return vec_upload_bytes(&idx->v, (const char*)host, first, n);
+}
+
+int fpgpu_vec_spmv(const fpgpu_ctx* ctx, const fpgpu_vec* vals, const fpgpu_idx* col_idx, size_t rows, size_t cols,
+                   size_t density, const fpgpu_vec* x, fpgpu_vec* y) {
+    CHECK(check_vec(ctx, vals, "vals"));
+    CHECK(check_vec(ctx, x, "x"));
+    CHECK(check_vec(ctx, y, "y"));
+    if (!col_idx) return fail(FPGPU_ERR_SHAPE, "null index vector");
+    if (x->n != cols) return fail(FPGPU_ERR_SHAPE, "spmv: x does not hold cols elements");
+    if (col_idx->v.n != vals->n) return fail(FPGPU_ERR_SHAPE, "spmv: values and column indices differ in length");
+    std::lock_guard<std::recursive_mutex> lock(g_mu);
+    return rowblock_product(vals, rows, density, y, 1, "spmv", [&](size_t pi, size_t prows, size_t, char* dst) {
+        const VecPart& a = vals->parts[pi];
+        if (prows == 0) return (int)FPGPU_OK;
+        const char *pc, *px;
+        CHECK(operand_ptr(&col_idx->v, vals, pi, "col_idx", &pc));
+        CHECK(whole_on_slot(x, a.slot, "x", &px));
+        return fpgpu_spmv_dev(ctx, a.ptr, (const uint32_t*)pc, prows, cols, density, px, dst, a.slot->stream);
     });
 }
 

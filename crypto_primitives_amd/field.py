@@ -221,6 +221,11 @@ class MontyField:
         check(self._lib.fpgpu_vec_matvec(self._h, A._h, rows, cols, x._h, y._h))
         return y
 
+    def spmv_vec(self, vals, col_idx, rows, cols, density, x, y):
+        """SparseMatrix times vector on handles: vals a DeviceVector (alloc_rows(rows, density)), col_idx a DeviceIndices."""
+        check(self._lib.fpgpu_vec_spmv(self._h, vals._h, col_idx._h, rows, cols, density, x._h, y._h))
+        return y
+
     def matmul_vec(self, A, B, C, m, k, n):
         check(self._lib.fpgpu_vec_matmul(self._h, A._h, B._h, C._h, m, k, n))
         return C

@@ -272,6 +272,26 @@ struct DeviceOps {
     void matmul(const DeviceVec& A, const DeviceVec& B, DeviceVec& C, size_t m, size_t k, size_t n) const {
         fpgpu_check(fpgpu_vec_matmul(ctx, A.raw(), B.raw(), C.raw(), m, k, n));
     }
+    // y = A x over SparseMatrix: values and column indices in two device containers with one row partition
+    void spmv(const DeviceVec& vals, const fpgpu_idx* col_idx, size_t rows, size_t cols, size_t density, const DeviceVec& x,
+              DeviceVec& y) const {
+        fpgpu_check(fpgpu_vec_spmv(ctx, vals.raw(), col_idx, rows, cols, density, x.raw(), y.raw()));
+    }
+};
+
+// Device-resident column indices of a SparseMatrix (fpgpu_idx), laid out like its values.
+class DeviceIndices {
+   public:
+    DeviceIndices(size_t rows, size_t density, Placement where) {
+        fpgpu_idx* raw = nullptr;
+        fpgpu_check(fpgpu_idx_alloc_rows(rows, density, (int)where, &raw));
+        h_.reset(raw, [](fpgpu_idx* i) { fpgpu_idx_free(i); });
+    }
+    void upload(const std::vector<uint32_t>& cols) { fpgpu_check(fpgpu_idx_upload(h_.get(), cols.data(), 0, cols.size())); }
+    const fpgpu_idx* raw() const { return h_.get(); }
+
+   private:
+    std::shared_ptr<fpgpu_idx> h_;
 };
 }  // namespace detail
 

@@ -100,3 +100,29 @@ class DeviceVector:
     def fill_random(self, seed):
         check(self._lib.fpgpu_vec_fill_random(self.field._h, self._h, seed))
         return self
+
+
+class DeviceIndices:
+    """An fpgpu_idx: the 32-bit column indices of a SparseMatrix (rows x density), laid out like its values."""
+
+    def __init__(self, rows, density, placement=PLACE_CURRENT):
+        self._lib = _lib.load()
+        h = ctypes.c_void_p()
+        check(self._lib.fpgpu_idx_alloc_rows(rows, density, placement, ctypes.byref(h)))
+        self._h, self.n = h, rows * density
+
+    def upload(self, col_idx, first=0):
+        c = np.ascontiguousarray(col_idx, dtype=np.uint32).reshape(-1)
+        check(self._lib.fpgpu_idx_upload(self._h, ctypes.c_void_p(c.ctypes.data), first, c.shape[0]))
+        return self
+
+    def free(self):
+        if getattr(self, "_h", None):
+            self._lib.fpgpu_idx_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

@@ -296,6 +296,17 @@ int fpgpu_vec_matvec(const fpgpu_ctx *ctx, const fpgpu_vec *A, size_t rows, size
 int fpgpu_vec_matmul(const fpgpu_ctx *ctx, const fpgpu_vec *A, const fpgpu_vec *B, fpgpu_vec *C, size_t m, size_t k,
                      size_t n);
 
+/* y = A x over SparseMatrix<T> (src/matrix.rs:46-61) on handles: `vals` holds rows * density values in
+ * row blocks (fpgpu_vec_alloc_rows(ctx, rows, density, placement)), `col_idx` the cells' 32-bit column
+ * indices in the same layout (an fpgpu_idx: same placements, 4-byte elements), x whole on every device
+ * that holds rows, y partitioned like the rows or replicated (then all-gathered as above). */
+typedef struct fpgpu_idx fpgpu_idx;
+int fpgpu_idx_alloc_rows(size_t rows, size_t density, int placement, fpgpu_idx **out);
+void fpgpu_idx_free(fpgpu_idx *idx);
+int fpgpu_idx_upload(fpgpu_idx *idx, const uint32_t *host, size_t first, size_t n);
+int fpgpu_vec_spmv(const fpgpu_ctx *ctx, const fpgpu_vec *vals, const fpgpu_idx *col_idx, size_t rows, size_t cols,
+                   size_t density, const fpgpu_vec *x, fpgpu_vec *y);
+
 /* ---- tuning / test hooks -----------------------------------------------------
  * No counterpart in the reference.  The hooks of INTEGRATION.md section 4 (FPGPU_GRID_CAP,
  * FPGPU_INV_C, FPGPU_MATVEC_MFMA, FPGPU_MATVEC_KSPLIT, FPGPU_MATVEC_T, FPGPU_MATMUL_MFMA,

@@ -18,6 +18,12 @@ pub struct fpgpu_vec {
     _private: [u8; 0],
 }
 
+/// Opaque `fpgpu_idx`: device-resident 32-bit column indices of a `SparseMatrix`, laid out like its values.
+#[repr(C)]
+pub struct fpgpu_idx {
+    _private: [u8; 0],
+}
+
 pub const FPGPU_OK: c_int = 0;
 /// Even or zero modulus: `FieldError::InvalidModulus` (src/field.rs:345-349).
 pub const FPGPU_ERR_INVALID_MODULUS: c_int = 1;
@@ -148,6 +154,12 @@ extern "C" {
                             y: *mut fpgpu_vec) -> c_int;
     pub fn fpgpu_vec_matmul(ctx: *const fpgpu_ctx, a: *const fpgpu_vec, b: *const fpgpu_vec, c: *mut fpgpu_vec, m: usize,
                             k: usize, n: usize) -> c_int;
+
+    pub fn fpgpu_idx_alloc_rows(rows: usize, density: usize, placement: c_int, out: *mut *mut fpgpu_idx) -> c_int;
+    pub fn fpgpu_idx_free(idx: *mut fpgpu_idx);
+    pub fn fpgpu_idx_upload(idx: *mut fpgpu_idx, host: *const u32, first: usize, n: usize) -> c_int;
+    pub fn fpgpu_vec_spmv(ctx: *const fpgpu_ctx, vals: *const fpgpu_vec, col_idx: *const fpgpu_idx, rows: usize, cols: usize,
+                          density: usize, x: *const fpgpu_vec, y: *mut fpgpu_vec) -> c_int;
 
     // ---- tuning / test hooks (process-wide; FPGPU_TUNING_DEFAULT restores the default)
     pub fn fpgpu_tuning_set(name: *const c_char, value: c_long) -> c_int;

@@ -86,6 +86,7 @@ _C_TO_RUST = {
     "const uint64_t *": "*const u64", "uint64_t *": "*mut u64", "const uint32_t *": "*const u32", "uint8_t *": "*mut u8",
     "const fpgpu_ctx *": "*const fpgpu_ctx", "fpgpu_ctx *": "*mut fpgpu_ctx", "fpgpu_ctx **": "*mut *mut fpgpu_ctx",
     "const fpgpu_vec *": "*const fpgpu_vec", "fpgpu_vec *": "*mut fpgpu_vec", "fpgpu_vec **": "*mut *mut fpgpu_vec",
+    "const fpgpu_idx *": "*const fpgpu_idx", "fpgpu_idx *": "*mut fpgpu_idx", "fpgpu_idx **": "*mut *mut fpgpu_idx",
 }
 
 

@@ -273,3 +273,33 @@ def test_layout_mismatches_are_errors(cpa, devices):
         a.download(first=50, n=51)
     with pytest.raises(cpa.FpgpuError, match="no such device"):
         V.alloc(f, 4, 99)
+
+
+@pytest.mark.parametrize("ids", [None, [0], [0, 0, 0]], ids=["unset", "list1_rccl", "list3same_copy"])
+@pytest.mark.parametrize("shape", [(300, 1000, 7), (5, 9, 3), (1, 4, 2), (70, 64, 0)])
+def test_sparse_matvec_on_handles(cpa, devices, ids, shape):
+    """SparseMatrix (src/matrix.rs:46-61) times vector with values and 32-bit column indices in
+    device-resident containers that share one row partition; y sharded like the rows and replicated
+    (all-gathered)."""
+    devices(ids)
+    rows, cols, density = shape
+    V = cpa.DeviceVector
+    place = cpa.PLACE_CURRENT if ids is None else cpa.PLACE_SHARDED
+    rep = cpa.PLACE_CURRENT if ids is None else cpa.PLACE_REPLICATED
+    rng = np.random.default_rng(rows + cols + density)
+    for name in ("bn254_fr", "goldilocks", "bls12_381_fq"):
+        f, o, p, n64 = _field(cpa, name)
+        hv = ints_to_array(synth_elements(p, n64, rows * density, 91), n64)
+        hx = ints_to_array(synth_elements(p, n64, cols, 92), n64)
+        col = rng.integers(0, cols, size=rows * density, dtype=np.uint32)
+        want = o.spmv(hv, col, rows, cols, density, hx)
+        vals = V.alloc_rows(f, rows, density, place).upload(hv)
+        idx = cpa.DeviceIndices(rows, density, place).upload(col)
+        x = V.from_host(f, hx, rep)
+        y = V.alloc_rows(f, rows, 1, place)
+        f.spmv_vec(vals, idx, rows, cols, density, x, y)
+        assert np.array_equal(y.download(), want), (name, "sharded y")
+        if ids is not None:
+            yr = V.alloc(f, rows, cpa.PLACE_REPLICATED)
+            f.spmv_vec(vals, idx, rows, cols, density, x, yr)
+            assert np.array_equal(yr.download(), want), (name, "replicated y")
