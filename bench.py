@@ -174,27 +174,31 @@ def main():
     # ---------------- secondary measurements ------------------------------------------
     if not args.no_extra:
         ksteps = max(3, min(args.steps, 10))
+        # three untimed launches before each secondary measurement: the sample gathered above (and every
+        # other host-side pause) lets the GPU clocks drop, and the first launches after a pause run up to
+        # 6 % slow (tools/probe_sqr_timing2.py: sqr 3.18 ms right after the gather, 3.00 ms from the next series on)
+        xwarm = 3
         for name, (fn, bytes_per) in ops.items():
             if name == args.workload:
                 continue
-            wall, kern = time_steps(fn, ksteps, 1)
+            wall, kern = time_steps(fn, ksteps, xwarm)
             extra[name] = {"Gelem_per_s": n * world * ksteps / wall / 1e9, "kernel_ms": kern * 1e3,
                            "hbm_GBps_per_gpu": bytes_per * n / kern / 1e9,
                            "hbm_frac": bytes_per * n / kern / 1e9 / HBM_PEAK_GBPS}
         # the remaining elementwise rows of SURVEY.md 8a (A4, A8): one read, one write
         for name, fn in (("neg", lambda: f.neg_dev(a, out)), ("to_mont", lambda: f.to_mont_dev(a, out)),
                          ("from_mont", lambda: f.from_mont_dev(a, out))):
-            wall, kern = time_steps(fn, ksteps, 1)
+            wall, kern = time_steps(fn, ksteps, xwarm)
             extra[name] = {"Gelem_per_s": n * world * ksteps / wall / 1e9, "kernel_ms": kern * 1e3,
                            "hbm_GBps_per_gpu": 64 * n / kern / 1e9, "hbm_frac": 64 * n / kern / 1e9 / HBM_PEAK_GBPS}
         # in place, a[i] *= b[i] (the reference's MulAssign<&Self>, crypto_bigint_const_monty.rs:337-347): the
         # same 96 algorithmic bytes per element, written to the lines just read
-        wall, kern = time_steps(lambda: f.mul_dev(out, b, out), ksteps, 1)
+        wall, kern = time_steps(lambda: f.mul_dev(out, b, out), ksteps, xwarm)
         extra["mul_assign_in_place"] = {"Gelem_per_s": n * world * ksteps / wall / 1e9, "kernel_ms": kern * 1e3,
                                         "hbm_GBps_per_gpu": 96 * n / kern / 1e9, "hbm_frac": 96 * n / kern / 1e9 / HBM_PEAK_GBPS}
         # register-resident dependent chain: the VALU-bound Gmul/s ("Mul assign" shape)
         nchain, iters = 1 << 22, 256
-        wall, kern = time_steps(lambda: f.mul_chain_dev(a[:nchain], b[:nchain], out[:nchain], iters), 5, 1)
+        wall, kern = time_steps(lambda: f.mul_chain_dev(a[:nchain], b[:nchain], out[:nchain], iters), 5, 2)
         gmul = nchain * iters / kern / 1e9
         # 136 = 2*8^2 + 8 multiplies of the reference's 32-bit-limb CIOS; the kernel
         # executes 171 = 2*9^2 + 9 on unsaturated 29-bit limbs (no carry adds), DESIGN.md section 4
@@ -265,7 +269,7 @@ def bench_batch_inv(args, world, rank, time_steps, primary, samples):
     flags = torch.empty(n, dtype=torch.uint8, device="cuda")
     ws = torch.empty(fq.inv_workspace_bytes(n), dtype=torch.uint8, device="cuda")
     steps = args.steps if primary else 5
-    wall, kern = time_steps(lambda: fq.inv_dev(x, out, flags, ws), steps, 1)
+    wall, kern = time_steps(lambda: fq.inv_dev(x, out, flags, ws), steps, max(1, args.warmup) if primary else 3)
     # property check: x * inv(x) == one wherever x != 0
     chk = fq.alloc(n)
     fq.mul_dev(x, out, chk)
@@ -326,7 +330,7 @@ def bench_matmul(args, world, rank, distributed, time_steps, primary, samples):
         dist.all_gather_into_tensor(C, C_local)
 
     steps = max(2, min(args.steps, 5)) if not primary else args.steps
-    wall, kern = time_steps(step, steps, 1)
+    wall, kern = time_steps(step, steps, max(1, args.warmup) if primary else 2)
     if rank == 0:   # twelve entries of C with their rows of A and columns of B, for the oracle in the CPU leg
         torch.cuda.synchronize()
         rs, cs = [0, rows // 2 + 1, rows - 1], [0, 1, dim // 2 + 3, dim - 1]
@@ -392,7 +396,7 @@ def bench_matvec(args, f, world, rank, distributed, time_steps, primary, samples
             dist.all_gather_into_tensor(y, y_local)
 
     steps = args.steps if primary else 5
-    wall, kern = time_steps(step, steps, 1)
+    wall, kern = time_steps(step, steps, max(1, args.warmup) if primary else 3)
     if rank == 0:   # three rows of A, x and their outputs for the oracle in the CPU leg
         import numpy as np
         torch.cuda.synchronize()
