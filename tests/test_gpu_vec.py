@@ -303,3 +303,29 @@ def test_sparse_matvec_on_handles(cpa, devices, ids, shape):
             yr = V.alloc(f, rows, cpa.PLACE_REPLICATED)
             f.spmv_vec(vals, idx, rows, cols, density, x, yr)
             assert np.array_equal(yr.download(), want), (name, "replicated y")
+
+
+@pytest.mark.parametrize("threads", [0, 1, 3])
+def test_staged_copies_round_trip_at_chunk_boundaries(cpa, tuning, threads):
+    """Uploads and downloads above 4 MiB go through the library's pinned staging buffers in 8 MiB chunks
+    filled / drained by copy threads (1 = plain hipMemcpy): sizes on, just below and just above chunk
+    boundaries, partial ranges, and the host-buffer entry points on the same sizes."""
+    if threads:
+        tuning("FPGPU_COPY_THREADS", threads)
+    f = cpa.MontyField(cpa.BN254_FR, 4)
+    rng = np.random.default_rng(threads)
+    chunk = (8 << 20) // 32
+    for n in (chunk - 1, chunk, chunk + 1, 2 * chunk, 3 * chunk + 7, (4 << 20) // 32, (4 << 20) // 32 - 1):
+        h = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64)
+        v = cpa.DeviceVector.from_host(f, h)
+        assert np.array_equal(v.download(), h), n
+        assert np.array_equal(v.download(first=5, n=n - 9), h[5:n - 4]), n
+        h2 = rng.integers(0, 1 << 63, size=(n - 3, 4), dtype=np.uint64)
+        v.upload(h2, first=3)
+        assert np.array_equal(v.download(first=3), h2) and np.array_equal(v.download(n=3), h[:3])
+    # host-buffer calls: neg(neg(x)) == x for canonical x, on a size that spans three chunks
+    n = 2 * chunk + 12345
+    x = rng.integers(0, 1 << 62, size=(n, 4), dtype=np.uint64)
+    x[:, 3] &= (1 << 60) - 1
+    assert np.array_equal(f.neg(f.neg(x)), x)
+    assert np.array_equal(f.sub(f.add(x, x[::-1].copy()), x[::-1].copy()), x)
