@@ -214,17 +214,7 @@ int host_binary(const fpgpu_ctx* ctx, const uint64_t* a, const uint64_t* b, uint
     if (n == 0) return FPGPU_OK;
     if (!a || !out || (has_b && !b)) return fail(FPGPU_ERR_SHAPE, "null host pointer");
     CHECK(require_device());
-    size_t bytes = n * ctx->n64 * 8;
-    DevBuf da, db, dout;
-    CHECK(da.alloc(bytes));
-    if (has_b) CHECK(db.alloc(bytes));
-    CHECK(dout.alloc(bytes));
-    CHECK(upload_staged(da.p, a, bytes, nullptr));
-    if (has_b) CHECK(upload_staged(db.p, b, bytes, nullptr));
-    CHECK(dev_call(da.p, db.p, dout.p));
-    HIP_TRY(hipStreamSynchronize(nullptr));
-    CHECK(download_staged(out, dout.p, bytes, nullptr));
-    return FPGPU_OK;
+    return host_stream_elementwise(a, has_b ? b : nullptr, out, n, (size_t)ctx->n64 * 8, dev_call);
 }
 
 }  // namespace
@@ -505,43 +495,43 @@ int fpgpu_fill_random_dev(const fpgpu_ctx* ctx, void* out, size_t n, uint64_t se
 // ---- host-buffer calls -----------------------------------------------------------------
 int fpgpu_mul(const fpgpu_ctx* ctx, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
     return host_binary(ctx, a, b, out, n, true,
-                       [&](void* da, void* db, void* dout) { return fpgpu_mul_dev(ctx, da, db, dout, n, nullptr); });
+                       [&](void* da, void* db, void* dout, size_t cnt, hipStream_t s) { return fpgpu_mul_dev(ctx, da, db, dout, cnt, s); });
 }
 int fpgpu_sqr(const fpgpu_ctx* ctx, const uint64_t* a, uint64_t* out, size_t n) {
     return host_binary(ctx, a, nullptr, out, n, false,
-                       [&](void* da, void*, void* dout) { return fpgpu_sqr_dev(ctx, da, dout, n, nullptr); });
+                       [&](void* da, void*, void* dout, size_t cnt, hipStream_t s) { return fpgpu_sqr_dev(ctx, da, dout, cnt, s); });
 }
 int fpgpu_add(const fpgpu_ctx* ctx, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
     return host_binary(ctx, a, b, out, n, true,
-                       [&](void* da, void* db, void* dout) { return fpgpu_add_dev(ctx, da, db, dout, n, nullptr); });
+                       [&](void* da, void* db, void* dout, size_t cnt, hipStream_t s) { return fpgpu_add_dev(ctx, da, db, dout, cnt, s); });
 }
 int fpgpu_sub(const fpgpu_ctx* ctx, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
     return host_binary(ctx, a, b, out, n, true,
-                       [&](void* da, void* db, void* dout) { return fpgpu_sub_dev(ctx, da, db, dout, n, nullptr); });
+                       [&](void* da, void* db, void* dout, size_t cnt, hipStream_t s) { return fpgpu_sub_dev(ctx, da, db, dout, cnt, s); });
 }
 int fpgpu_neg(const fpgpu_ctx* ctx, const uint64_t* a, uint64_t* out, size_t n) {
     return host_binary(ctx, a, nullptr, out, n, false,
-                       [&](void* da, void*, void* dout) { return fpgpu_neg_dev(ctx, da, dout, n, nullptr); });
+                       [&](void* da, void*, void* dout, size_t cnt, hipStream_t s) { return fpgpu_neg_dev(ctx, da, dout, cnt, s); });
 }
 int fpgpu_to_mont(const fpgpu_ctx* ctx, const uint64_t* a, uint64_t* out, size_t n) {
     return host_binary(ctx, a, nullptr, out, n, false,
-                       [&](void* da, void*, void* dout) { return fpgpu_to_mont_dev(ctx, da, dout, n, nullptr); });
+                       [&](void* da, void*, void* dout, size_t cnt, hipStream_t s) { return fpgpu_to_mont_dev(ctx, da, dout, cnt, s); });
 }
 int fpgpu_from_mont(const fpgpu_ctx* ctx, const uint64_t* a, uint64_t* out, size_t n) {
     return host_binary(ctx, a, nullptr, out, n, false,
-                       [&](void* da, void*, void* dout) { return fpgpu_from_mont_dev(ctx, da, dout, n, nullptr); });
+                       [&](void* da, void*, void* dout, size_t cnt, hipStream_t s) { return fpgpu_from_mont_dev(ctx, da, dout, cnt, s); });
 }
 int fpgpu_mul_chain(const fpgpu_ctx* ctx, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n,
                     uint32_t iters) {
-    return host_binary(ctx, a, b, out, n, true, [&](void* da, void* db, void* dout) {
-        return fpgpu_mul_chain_dev(ctx, da, db, dout, n, iters, nullptr);
+    return host_binary(ctx, a, b, out, n, true, [&](void* da, void* db, void* dout, size_t cnt, hipStream_t s) {
+        return fpgpu_mul_chain_dev(ctx, da, db, dout, cnt, iters, s);
     });
 }
 
 int fpgpu_pow(const fpgpu_ctx* ctx, const uint64_t* a, const uint64_t* exponent_le, uint32_t exponent_words,
               uint64_t* out, size_t n) {
-    return host_binary(ctx, a, nullptr, out, n, false, [&](void* da, void*, void* dout) {
-        return fpgpu_pow_dev(ctx, da, exponent_le, exponent_words, dout, n, nullptr);
+    return host_binary(ctx, a, nullptr, out, n, false, [&](void* da, void*, void* dout, size_t cnt, hipStream_t s) {
+        return fpgpu_pow_dev(ctx, da, exponent_le, exponent_words, dout, cnt, s);
     });
 }
 

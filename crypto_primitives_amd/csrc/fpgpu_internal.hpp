@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <functional>
 #include <string>
 
 #include "../../include/fpgpu.h"
@@ -18,6 +19,11 @@ int hip_fail(hipError_t e, const char* what);     // FPGPU_ERR_HIP with the runt
 // (fpgpu_stage.hip); both return when the host buffer is the caller's again / holds the data.
 int upload_staged(void* dev, const void* host, size_t bytes, hipStream_t stream);
 int download_staged(void* host, const void* dev, size_t bytes, hipStream_t stream);
+// out[i] = op(a[i], b[i]) on host arrays of n elements of esz bytes (b may be NULL): `call` queues the
+// operation for `count` elements in device memory on `stream`.  Chunked, full duplex, no allocation per
+// call above 4 MiB; synchronous.
+using ChunkCall = std::function<int(void* da, void* db, void* dout, size_t count, hipStream_t stream)>;
+int host_stream_elementwise(const void* a, const void* b, void* out, size_t n, size_t esz, const ChunkCall& call);
 
 }  // namespace fpgpu
 

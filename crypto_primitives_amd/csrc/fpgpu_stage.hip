@@ -4,9 +4,20 @@
 // hipMemcpy from such memory is staged by the runtime through pinned buffers on ONE thread and reaches
 // ~30 GB/s to the device and ~18 GB/s back on the MI355X boxes (tools/ubench_pcie.hip), and the caller's
 // memory cannot be pinned in place there (hipHostRegister is refused for ordinary users).  Here the
-// staging is the library's: two pinned buffers per direction, filled / drained by a few host threads
-// while the DMA engine moves the previous chunk, so a transfer runs at the slower of "several cores of
-// memcpy" and the PCIe link instead of at one core of memcpy.
+// staging is the library's, organised as a few independent LANES: lane t of T owns chunks t, t + T,
+// t + 2T, ... of the transfer, a host thread, and two pinned + two device buffers.  A lane copies its
+// chunk into pinned memory, queues the DMA and goes on with its next chunk while the DMA engine works;
+// no lane waits for another, so T cores of memcpy feed the link, and copies in opposite directions
+// overlap on the two DMA directions of PCIe.  Measured on the MI355X boxes (tools/time_xfer.py): copies
+// TO the device must all be queued on ONE stream -- with a stream per lane, a hipMemcpyAsync now and
+// then blocks its caller for the length of the whole transfer (6 ms for 128 MiB) and the rate falls from
+// 43 to 18-25 GB/s -- while copies FROM the device are fastest on a stream per lane (40-45 GB/s against
+// 30 on one); 4-6 MiB per DMA to the device (2 MiB: 38 GB/s, 6 MiB: 43-45).
+//
+// The elementwise host calls (fpgpu_mul, fpgpu_add, ... fpgpu_pow) never hold a whole operand on the
+// device: a lane uploads a chunk of a and b, runs the kernel on it, downloads the chunk of the result and
+// copies it out while its next chunk is in flight -- full duplex, no hipMalloc per call, and host arrays
+// larger than HBM work.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -24,13 +35,13 @@ namespace fpgpu {
 
 namespace {
 
-// ---- a few persistent copy threads -------------------------------------------------------------
-class CopyPool {
+// ---- persistent host threads: run(parts, fn) calls fn(0) here and fn(1..parts-1) on workers ----------
+class WorkerPool {
    public:
-    explicit CopyPool(int workers) {
-        for (int i = 0; i < workers; i++) threads_.emplace_back([this] { run(); });
+    explicit WorkerPool(int workers) {
+        for (int i = 0; i < workers; i++) threads_.emplace_back([this] { loop(); });
     }
-    ~CopyPool() {
+    ~WorkerPool() {
         {
             std::lock_guard<std::mutex> l(mu_);
             stop_ = true;
@@ -38,156 +49,328 @@ class CopyPool {
         cv_.notify_all();
         for (auto& t : threads_) t.join();
     }
-    // dst <- src, split over the workers and the calling thread
-    void copy(void* dst, const void* src, size_t bytes) {
-        const size_t parts = threads_.size() + 1;
-        if (parts == 1 || bytes < ((size_t)1 << 20)) {
-            std::memcpy(dst, src, bytes);
+    int width() const { return (int)threads_.size() + 1; }
+    void run(int parts, const std::function<void(int)>& fn) {
+        parts = std::min(parts, width());
+        if (parts <= 1) {
+            fn(0);
             return;
         }
-        const size_t piece = ((bytes / parts) + 4095) & ~(size_t)4095;
         {
             std::lock_guard<std::mutex> l(mu_);
-            for (size_t i = 1; i < parts; i++) {
-                const size_t off = i * piece;
-                if (off >= bytes) break;
-                jobs_.push_back({(char*)dst + off, (const char*)src + off, std::min(piece, bytes - off)});
-                pending_++;
-            }
+            fn_ = &fn;
+            next_ = 1;
+            parts_ = parts;
+            pending_ = parts - 1;
         }
         cv_.notify_all();
-        std::memcpy(dst, src, std::min(piece, bytes));
+        fn(0);
         std::unique_lock<std::mutex> l(mu_);
         done_.wait(l, [this] { return pending_ == 0; });
+        fn_ = nullptr;
     }
 
    private:
-    struct Job { char* dst; const char* src; size_t bytes; };
-    void run() {
+    void loop() {
         for (;;) {
-            Job j;
+            int part;
+            const std::function<void(int)>* fn;
             {
                 std::unique_lock<std::mutex> l(mu_);
-                cv_.wait(l, [this] { return stop_ || !jobs_.empty(); });
-                if (stop_ && jobs_.empty()) return;
-                j = jobs_.back();
-                jobs_.pop_back();
+                cv_.wait(l, [this] { return stop_ || (fn_ && next_ < parts_); });
+                if (stop_) return;
+                part = next_++;
+                fn = fn_;
             }
-            std::memcpy(j.dst, j.src, j.bytes);
+            (*fn)(part);
             {
                 std::lock_guard<std::mutex> l(mu_);
-                pending_--;
+                if (--pending_ == 0) done_.notify_all();
             }
-            done_.notify_all();
         }
     }
     std::vector<std::thread> threads_;
-    std::vector<Job> jobs_;
     std::mutex mu_;
     std::condition_variable cv_, done_;
-    size_t pending_ = 0;
+    const std::function<void(int)>* fn_ = nullptr;
+    int next_ = 0, parts_ = 0, pending_ = 0;
     bool stop_ = false;
 };
 
-constexpr size_t kChunk = (size_t)8 << 20;   // bytes per staging buffer
+constexpr size_t kLaneChunk = (size_t)2 << 20;   // bytes per operand per pipeline slot
+constexpr size_t kSlotBytes = 3 * kLaneChunk;    // a | b | out
+constexpr size_t kUpChunk = kSlotBytes;           // plain uploads: one DMA per slot
+constexpr size_t kDownChunk = kLaneChunk;        // plain downloads: small chunks, every lane's stream busy early
 constexpr size_t kMinStaged = (size_t)4 << 20;   // below this a plain hipMemcpy is as fast
+constexpr int kMaxLanes = 16;
 
-struct Stage {
-    std::mutex mu;   // one staged transfer at a time (the pinned buffers are shared)
-    char* pin[2] = {nullptr, nullptr};
-    hipEvent_t ev[2] = {nullptr, nullptr};
-    CopyPool* pool = nullptr;
-    bool ready = false;
+struct Lane {
+    hipStream_t stream = nullptr;                  // copies from the device
+    hipEvent_t ev[2] = {nullptr, nullptr};         // slot s: its last DMA is through
+    hipEvent_t uploaded[2] = {nullptr, nullptr};   // slot s: its operands are on the device
+    hipEvent_t computed[2] = {nullptr, nullptr};   // slot s: its kernel is through
+    char* dev[2] = {nullptr, nullptr};   // kSlotBytes each, on this device (elementwise pipeline only)
 };
-Stage g_stage;
+struct DeviceLanes {
+    int device = -1;
+    hipEvent_t order = nullptr;   // "everything queued on the caller's stream so far"
+    hipStream_t up = nullptr;     // every copy to the device -- see the header
+    hipStream_t compute = nullptr;   // the pipeline's kernels (on `up` they would hold back the next copy)
+    std::mutex issue;             // one lane at a time queues on `up` (keeps a slot's commands together)
+    std::vector<Lane> lanes;
+};
+struct Stage {
+    std::mutex mu;   // one staged transfer at a time: the pinned buffers and the lanes are shared
+    WorkerPool* pool = nullptr;
+    char* pin[kMaxLanes][2] = {};   // kSlotBytes each, portable: every device's lane t uses pin[t]
+    int pinned_lanes = 0;
+    std::vector<DeviceLanes*> devices;
+};
+Stage g_stage;   // never torn down: the threads, buffers and streams live until the process ends
 
-int stage_init() {
-    if (g_stage.ready) return FPGPU_OK;
-    for (int i = 0; i < 2; i++) {
-        HIP_TRY(hipHostMalloc((void**)&g_stage.pin[i], kChunk, hipHostMallocPortable));
-        HIP_TRY(hipEventCreateWithFlags(&g_stage.ev[i], hipEventDisableTiming));
-    }
+// how many lanes a transfer uses: FPGPU_COPY_THREADS, else by the host's core count (measured on the
+// MI355X boxes, fpgpu_mul over 2^22 BN254 elements -- see DESIGN.md section 6)
+int lanes_wanted() {
     long t = tuning().copy_threads;
     if (t <= 0) {
         const unsigned hw = std::thread::hardware_concurrency();
-        t = hw >= 16 ? 6 : (hw >= 8 ? 4 : (hw >= 4 ? 2 : 1));   // measured on the MI355X boxes: 1 thread 0.18 G elem/s
-                                                                // for fpgpu_mul, 2: 0.31, 4: 0.37, 8: 0.39, 12: 0.36
+        t = hw >= 16 ? 6 : (hw >= 8 ? 4 : (hw >= 4 ? 2 : 1));
     }
-    g_stage.pool = new CopyPool((int)std::min<long>(t, 16) - 1);
-    g_stage.ready = true;
+    return (int)std::min<long>(t, kMaxLanes);
+}
+
+// the current device's lanes, grown to `lanes` (caller holds g_stage.mu)
+int acquire(int lanes, DeviceLanes** out) {
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    DeviceLanes* d = nullptr;
+    for (auto* c : g_stage.devices)
+        if (c->device == dev) d = c;
+    if (!d) {
+        d = new DeviceLanes();
+        d->device = dev;
+        HIP_TRY(hipEventCreateWithFlags(&d->order, hipEventDisableTiming));
+        HIP_TRY(hipStreamCreateWithFlags(&d->up, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&d->compute, hipStreamNonBlocking));
+        g_stage.devices.push_back(d);
+    }
+    for (; g_stage.pinned_lanes < lanes; g_stage.pinned_lanes++)
+        for (int s = 0; s < 2; s++)
+            HIP_TRY(hipHostMalloc((void**)&g_stage.pin[g_stage.pinned_lanes][s], kSlotBytes, hipHostMallocPortable));
+    while ((int)d->lanes.size() < lanes) {
+        Lane l;
+        HIP_TRY(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
+        for (int s = 0; s < 2; s++) {
+            HIP_TRY(hipEventCreateWithFlags(&l.ev[s], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&l.uploaded[s], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&l.computed[s], hipEventDisableTiming));
+        }
+        d->lanes.push_back(l);
+    }
+    if (!g_stage.pool || g_stage.pool->width() < lanes) {
+        delete g_stage.pool;
+        g_stage.pool = new WorkerPool(lanes - 1);
+    }
+    *out = d;
     return FPGPU_OK;
 }
+
+int ensure_device_slots(DeviceLanes* d, int lanes) {
+    for (int t = 0; t < lanes; t++)
+        for (int s = 0; s < 2; s++)
+            if (!d->lanes[t].dev[s]) HIP_TRY(hipMalloc((void**)&d->lanes[t].dev[s], kSlotBytes));
+    return FPGPU_OK;
+}
+
+// A lane's failure reaches the calling thread (the message of fail() is thread-local).
+struct LaneStatus {
+    std::mutex mu;
+    int code = FPGPU_OK;
+    std::string msg;
+    void note(int rc) {
+        if (rc == FPGPU_OK) return;
+        std::lock_guard<std::mutex> l(mu);
+        if (code == FPGPU_OK) {
+            code = rc;
+            msg = g_last_error;
+        }
+    }
+    int result() { return code == FPGPU_OK ? FPGPU_OK : fail(code, msg); }
+};
+
+// Runs body(lane index) on `lanes` threads, each with `device` current; a failing lane drains its
+// stream before it returns so that no DMA is left running on the shared buffers.
+template <typename Body>
+int run_lanes(DeviceLanes* d, int lanes, Body&& body) {
+    LaneStatus st;
+    g_stage.pool->run(lanes, [&](int t) {
+        int rc = FPGPU_OK;
+        hipError_t e = t == 0 ? hipSuccess : hipSetDevice(d->device);   // part 0 is the calling thread
+        if (e != hipSuccess) rc = hip_fail(e, "hipSetDevice");
+        if (rc == FPGPU_OK) rc = body(t);
+        if (rc != FPGPU_OK) {
+            (void)hipStreamSynchronize(d->up);
+            (void)hipStreamSynchronize(d->compute);
+            (void)hipStreamSynchronize(d->lanes[t].stream);
+        }
+        st.note(rc);
+    });
+    return st.result();
+}
+
+inline size_t lane_chunks(size_t chunks, int t, int T) { return chunks > (size_t)t ? (chunks - t + T - 1) / T : 0; }
+
+int lane_upload(DeviceLanes* d, int t, int T, char* dev, const char* host, size_t bytes) {
+    Lane& L = d->lanes[t];
+    const size_t mine = lane_chunks((bytes + kUpChunk - 1) / kUpChunk, t, T);
+    for (size_t j = 0; j < mine; j++) {
+        const int s = (int)(j & 1);
+        const size_t off = (t + j * T) * kUpChunk, sz = std::min(kUpChunk, bytes - off);
+        if (j >= 2) HIP_TRY(hipEventSynchronize(L.ev[s]));   // the DMA out of this buffer is through
+        std::memcpy(g_stage.pin[t][s], host + off, sz);
+        std::lock_guard<std::mutex> issue(d->issue);
+        HIP_TRY(hipMemcpyAsync(dev + off, g_stage.pin[t][s], sz, hipMemcpyHostToDevice, d->up));
+        HIP_TRY(hipEventRecord(L.ev[s], d->up));
+    }
+    for (size_t j = mine > 2 ? mine - 2 : 0; j < mine; j++) HIP_TRY(hipEventSynchronize(L.ev[j & 1]));
+    return FPGPU_OK;
+}
+
+int lane_download(DeviceLanes* d, int t, int T, char* host, const char* dev, size_t bytes) {
+    Lane& L = d->lanes[t];
+    HIP_TRY(hipStreamWaitEvent(L.stream, d->order, 0));
+    const size_t mine = lane_chunks((bytes + kDownChunk - 1) / kDownChunk, t, T);
+    auto issue = [&](size_t j) -> int {
+        const int s = (int)(j & 1);
+        const size_t off = (t + j * T) * kDownChunk, sz = std::min(kDownChunk, bytes - off);
+        HIP_TRY(hipMemcpyAsync(g_stage.pin[t][s], dev + off, sz, hipMemcpyDeviceToHost, L.stream));
+        HIP_TRY(hipEventRecord(L.ev[s], L.stream));
+        return FPGPU_OK;
+    };
+    if (mine) CHECK(issue(0));
+    for (size_t j = 0; j < mine; j++) {
+        const int s = (int)(j & 1);
+        if (j + 1 < mine) CHECK(issue(j + 1));   // the other buffer: drained in the previous round
+        HIP_TRY(hipEventSynchronize(L.ev[s]));
+        const size_t off = (t + j * T) * kDownChunk, sz = std::min(kDownChunk, bytes - off);
+        std::memcpy(host + off, g_stage.pin[t][s], sz);
+    }
+    return FPGPU_OK;
+}
+
+// chunk j of lane t: up (a | b in one DMA) on the upload stream, kernel on the compute stream, down on the lane's own;
+// two rounds later the lane copies the result out of the pinned buffer and reuses the slot.
+int lane_elementwise(DeviceLanes* d, int t, int T, const char* a, const char* b, char* out, size_t n, size_t esz,
+                     size_t per, const ChunkCall& call) {
+    Lane& L = d->lanes[t];
+    const size_t mine = lane_chunks((n + per - 1) / per, t, T);
+    for (size_t j = 0; j < mine + 2; j++) {
+        const int s = (int)(j & 1);
+        char* pin = g_stage.pin[t][s];
+        if (j >= 2) {
+            const size_t first = (t + (j - 2) * T) * per, cnt = std::min(per, n - first);
+            HIP_TRY(hipEventSynchronize(L.ev[s]));
+            std::memcpy(out + first * esz, pin + 2 * kLaneChunk, cnt * esz);
+        }
+        if (j < mine) {
+            const size_t first = (t + j * T) * per, cnt = std::min(per, n - first), bytes = cnt * esz;
+            const size_t boff = b ? (bytes + 255) & ~(size_t)255 : 0;   // b right behind a: one DMA for both
+            std::memcpy(pin, a + first * esz, bytes);
+            if (b) std::memcpy(pin + boff, b + first * esz, bytes);
+            {
+                std::lock_guard<std::mutex> issue(d->issue);
+                HIP_TRY(hipMemcpyAsync(L.dev[s], pin, boff + bytes, hipMemcpyHostToDevice, d->up));
+                HIP_TRY(hipEventRecord(L.uploaded[s], d->up));
+                HIP_TRY(hipStreamWaitEvent(d->compute, L.uploaded[s], 0));
+                CHECK(call(L.dev[s], b ? L.dev[s] + boff : nullptr, L.dev[s] + 2 * kLaneChunk, cnt, d->compute));
+                HIP_TRY(hipEventRecord(L.computed[s], d->compute));
+            }
+            HIP_TRY(hipStreamWaitEvent(L.stream, L.computed[s], 0));
+            HIP_TRY(hipMemcpyAsync(pin + 2 * kLaneChunk, L.dev[s] + 2 * kLaneChunk, bytes, hipMemcpyDeviceToHost, L.stream));
+            HIP_TRY(hipEventRecord(L.ev[s], L.stream));
+        }
+    }
+    return FPGPU_OK;
+}
+
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() {
+        if (p) (void)hipFree(p);
+    }
+    int alloc(size_t bytes) {
+        hipError_t e = hipMalloc(&p, std::max<size_t>(bytes, 16));
+        if (e != hipSuccess) {
+            p = nullptr;
+            return hip_fail(e, "hipMalloc");
+        }
+        return FPGPU_OK;
+    }
+};
 
 }  // namespace
 
-// Events are created on whatever device is current at first use; HIP events may only be recorded on
-// streams of their own device, so the two helpers below re-create them when the device differs.
-static int g_stage_device = -1;
-static int stage_for_current_device() {
-    int dev = 0;
-    HIP_TRY(hipGetDevice(&dev));
-    CHECK(stage_init());
-    if (g_stage_device != dev) {
-        for (int i = 0; i < 2; i++) {
-            if (g_stage.ev[i]) (void)hipEventDestroy(g_stage.ev[i]);
-            HIP_TRY(hipEventCreateWithFlags(&g_stage.ev[i], hipEventDisableTiming));
-        }
-        g_stage_device = dev;
-    }
-    return FPGPU_OK;
-}
-
-// dev <- host (pageable), on `stream` of the current device; returns when `host` is the caller's again
-// (the last chunks may still be in flight on `stream`: later work on that stream is ordered after them).
+// dev <- host (pageable), ordered after everything queued on `stream` of the current device; returns when
+// the data is in device memory (so later work on any stream sees it and `host` is the caller's again).
 int upload_staged(void* dev, const void* host, size_t bytes, hipStream_t stream) {
     if (bytes == 0) return FPGPU_OK;
-    if (bytes < kMinStaged || tuning().copy_threads == 1) {
+    const int lanes = lanes_wanted();
+    if (bytes < kMinStaged || lanes == 1) {
         HIP_TRY(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         return FPGPU_OK;
     }
     std::lock_guard<std::mutex> lock(g_stage.mu);
-    CHECK(stage_for_current_device());
-    size_t k = 0;
-    for (size_t off = 0; off < bytes; off += kChunk, k++) {
-        const int s = (int)(k & 1);
-        const size_t sz = std::min(kChunk, bytes - off);
-        if (k >= 2) HIP_TRY(hipEventSynchronize(g_stage.ev[s]));   // the DMA out of this buffer is through
-        g_stage.pool->copy(g_stage.pin[s], (const char*)host + off, sz);
-        HIP_TRY(hipMemcpyAsync((char*)dev + off, g_stage.pin[s], sz, hipMemcpyHostToDevice, stream));
-        HIP_TRY(hipEventRecord(g_stage.ev[s], stream));
-    }
-    // the pinned buffers are reused by the next transfer: wait until the DMA engine has read them
-    HIP_TRY(hipEventSynchronize(g_stage.ev[0]));
-    if (k > 1) HIP_TRY(hipEventSynchronize(g_stage.ev[1]));
-    return FPGPU_OK;
+    DeviceLanes* d = nullptr;
+    CHECK(acquire(lanes, &d));
+    HIP_TRY(hipEventRecord(d->order, stream));
+    HIP_TRY(hipStreamWaitEvent(d->up, d->order, 0));
+    return run_lanes(d, lanes, [&](int t) { return lane_upload(d, t, lanes, (char*)dev, (const char*)host, bytes); });
 }
 
 // host (pageable) <- dev, after everything queued on `stream`; returns when `host` holds the data.
 int download_staged(void* host, const void* dev, size_t bytes, hipStream_t stream) {
     if (bytes == 0) return FPGPU_OK;
-    if (bytes < kMinStaged || tuning().copy_threads == 1) {
+    const int lanes = lanes_wanted();
+    if (bytes < kMinStaged || lanes == 1) {
         HIP_TRY(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         return FPGPU_OK;
     }
     std::lock_guard<std::mutex> lock(g_stage.mu);
-    CHECK(stage_for_current_device());
-    const size_t chunks = (bytes + kChunk - 1) / kChunk;
-    auto issue = [&](size_t k) -> int {
-        const size_t off = k * kChunk, sz = std::min(kChunk, bytes - off);
-        HIP_TRY(hipMemcpyAsync(g_stage.pin[k & 1], (const char*)dev + off, sz, hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipEventRecord(g_stage.ev[k & 1], stream));
+    DeviceLanes* d = nullptr;
+    CHECK(acquire(lanes, &d));
+    HIP_TRY(hipEventRecord(d->order, stream));
+    return run_lanes(d, lanes, [&](int t) { return lane_download(d, t, lanes, (char*)host, (const char*)dev, bytes); });
+}
+
+// out[i] = op(a[i], b[i]) for host arrays: `call(da, db, dout, count, stream)` queues the operation on
+// `count` elements that lie in device memory (db == nullptr when b is).  Small batches, or one copy
+// thread: whole operands on the device through plain copies; otherwise the chunk pipeline above.
+int host_stream_elementwise(const void* a, const void* b, void* out, size_t n, size_t esz, const ChunkCall& call) {
+    if (n == 0) return FPGPU_OK;
+    const int lanes = lanes_wanted();
+    const size_t bytes = n * esz;
+    if (bytes < kMinStaged || lanes == 1) {
+        DevBuf da, db, dout;
+        CHECK(da.alloc(bytes));
+        if (b) CHECK(db.alloc(bytes));
+        CHECK(dout.alloc(bytes));
+        HIP_TRY(hipMemcpyAsync(da.p, a, bytes, hipMemcpyHostToDevice, nullptr));
+        if (b) HIP_TRY(hipMemcpyAsync(db.p, b, bytes, hipMemcpyHostToDevice, nullptr));
+        CHECK(call(da.p, db.p, dout.p, n, nullptr));
+        HIP_TRY(hipMemcpyAsync(out, dout.p, bytes, hipMemcpyDeviceToHost, nullptr));
+        HIP_TRY(hipStreamSynchronize(nullptr));
         return FPGPU_OK;
-    };
-    CHECK(issue(0));
-    for (size_t k = 0; k < chunks; k++) {
-        if (k + 1 < chunks) CHECK(issue(k + 1));   // the other buffer: drained in the previous iteration
-        HIP_TRY(hipEventSynchronize(g_stage.ev[k & 1]));
-        const size_t off = k * kChunk, sz = std::min(kChunk, bytes - off);
-        g_stage.pool->copy((char*)host + off, g_stage.pin[k & 1], sz);
     }
-    return FPGPU_OK;
+    std::lock_guard<std::mutex> lock(g_stage.mu);
+    DeviceLanes* d = nullptr;
+    CHECK(acquire(lanes, &d));
+    CHECK(ensure_device_slots(d, lanes));
+    const size_t per = std::max<size_t>((kLaneChunk / esz) & ~(size_t)31, 32);   // whole elements, 256-byte multiples
+    return run_lanes(d, lanes, [&](int t) {
+        return lane_elementwise(d, t, lanes, (const char*)a, (const char*)b, (char*)out, n, esz, per, call);
+    });
 }
 
 }  // namespace fpgpu

@@ -29,10 +29,15 @@
  * Device pointers must be 16-byte aligned (8-byte for n64 odd).  Every *_dev
  * call is asynchronous on `stream` (a hipStream_t, NULL = default stream) of the
  * current HIP device and allocates nothing.  The host-buffer calls are
- * synchronous, run on the current device, and stage through device memory they
- * allocate and free themselves; their host <-> device copies go through pinned
- * staging buffers of the library, filled and drained by a few host threads
- * (pageable caller memory cannot be pinned in place).
+ * synchronous and run on the current device; their host <-> device copies go
+ * through pinned staging buffers of the library, filled and drained by a few
+ * host threads (pageable caller memory cannot be pinned in place).  The
+ * elementwise ones (fpgpu_mul ... fpgpu_pow) stream their operands through the
+ * device in chunks -- copy in, kernel and copy out overlap, `out` may be `a`
+ * or `b`, and the arrays may exceed device memory; the others hold whole
+ * operands in device memory they allocate and free themselves.  The library
+ * keeps 72 MiB of pinned host memory, and 72 MiB on each device used this way,
+ * until the process ends (FPGPU_COPY_THREADS = 6; 12 MiB each per thread).
  */
 #ifndef FPGPU_H
 #define FPGPU_H

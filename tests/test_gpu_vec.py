@@ -329,3 +329,43 @@ def test_staged_copies_round_trip_at_chunk_boundaries(cpa, tuning, threads):
     x[:, 3] &= (1 << 60) - 1
     assert np.array_equal(f.neg(f.neg(x)), x)
     assert np.array_equal(f.sub(f.add(x, x[::-1].copy()), x[::-1].copy()), x)
+
+
+@pytest.mark.parametrize("threads", [0, 2, 5])
+@pytest.mark.parametrize("name,n64,n", [("goldilocks", 1, (1 << 20) + 77), ("bn254_fr", 4, 3 * 65536 * 3 + 1),
+                                        ("bls12_381_fq", 6, 200001), ("p511", 8, 150000 + 31)])
+def test_host_calls_chunk_pipeline_equals_whole_batch(cpa, tuning, threads, name, n64, n):
+    """Above 4 MiB the elementwise host-buffer calls run as a chunk pipeline on several lanes (upload a|b,
+    kernel, download, per 2 MiB chunk, each lane on its own thread and stream).  Every op must equal the same
+    kernel run once over the whole batch in HBM (handles), a sample must equal the oracle, and writing
+    the result over an operand (out == a) must work."""
+    from oracle.fp_oracle import Oracle
+    if threads:
+        tuning("FPGPU_COPY_THREADS", threads)
+    p = {"goldilocks": cpa.GOLDILOCKS, "bn254_fr": cpa.BN254_FR, "bls12_381_fq": cpa.BLS12_381_FQ, "p511": 2**511 - 187}[name]
+    f, o = cpa.MontyField(p, n64), Oracle(p, n64)
+    V = cpa.DeviceVector
+    va, vb, vo = V.alloc(f, n).fill_random(11), V.alloc(f, n).fill_random(12), V.alloc(f, n)
+    a, b = va.download(), vb.download()
+    assert a.nbytes >= (4 << 20)
+    sl = slice(n - 300, n)     # the ragged tail chunk
+    for host, vec, orc, binary in ((f.mul, f.mul_vec, o.mul, True), (f.add, f.add_vec, o.add, True),
+                                   (f.sub, f.sub_vec, o.sub, True), (f.sqr, f.sqr_vec, o.sqr, False),
+                                   (f.neg, f.neg_vec, o.neg, False), (f.project, f.project_vec, o.to_mont, False),
+                                   (f.lift, f.lift_vec, o.from_mont, False)):
+        got = host(a, b) if binary else host(a)
+        (vec(va, vb, vo) if binary else vec(va, vo))
+        assert np.array_equal(got, vo.download()), host.__name__
+        assert np.array_equal(got[sl], orc(a[sl], b[sl]) if binary else orc(a[sl])), host.__name__
+    got = f.mul_chain(a, b, 5)
+    f.mul_chain_vec(va, vb, vo, 5)
+    assert np.array_equal(got, vo.download())
+    got = f.pow(a, 65537)
+    f.pow_vec(va, 65537, vo)
+    assert np.array_equal(got, vo.download())
+    # in place through the C ABI: out is a
+    lib = cpa.load()
+    a2 = a.copy()
+    assert lib.fpgpu_mul(f._h, a2.ctypes.data, b.ctypes.data, a2.ctypes.data, n) == 0
+    f.mul_vec(va, vb, vo)
+    assert np.array_equal(a2, vo.download())
