@@ -294,6 +294,7 @@ class DeviceIndices {
     std::shared_ptr<fpgpu_idx> h_;
 };
 }  // namespace detail
+using detail::DeviceIndices;
 
 // ---- MontyFieldElement<LIMBS> (repr(transparent) over Uint) ------------------------------
 template <size_t LIMBS>
@@ -516,6 +517,18 @@ class MontyField {
     // y = A x with A in row blocks over the device list, x whole on every device; a replicated y is all-gathered
     void matvec(const DeviceVec& A, size_t rows, size_t cols, const DeviceVec& x, DeviceVec& y) const { on_device().matvec(A, rows, cols, x, y); }
     void matmul(const DeviceVec& A, const DeviceVec& B, DeviceVec& C, size_t m, size_t k, size_t n) const { on_device().matmul(A, B, C, m, k, n); }
+    // SparseMatrix on the device: its values in row blocks (a DeviceVec of rows x density) and its column indices
+    std::pair<DeviceVec, DeviceIndices> to_device(const SparseMatrix<Element>& A, Placement where) const {
+        std::vector<Element> vals(A.cells.size());
+        std::vector<uint32_t> cols(A.cells.size());
+        for (size_t i = 0; i < A.cells.size(); i++) { cols[i] = (uint32_t)A.cells[i].first; vals[i] = A.cells[i].second; }
+        DeviceIndices idx(A.num_rows, A.density, where);
+        idx.upload(cols);
+        return {to_device(vals, where, A.density), idx};
+    }
+    void spmv(const std::pair<DeviceVec, DeviceIndices>& A, size_t rows, size_t cols, size_t density, const DeviceVec& x, DeviceVec& y) const {
+        on_device().spmv(A.first, A.second.raw(), rows, cols, density, x, y);
+    }
 
    private:
     static uint64_t* w(Element& e) { return e.v.words.data(); }

@@ -296,6 +296,14 @@ static void test_gpu_device_vectors() {
         DeviceVec dy = f.alloc_device(rows, layout == 0 ? Placement::Current : Placement::Replicated);
         f.matvec(dA, rows, cols, dx, dy);
         CHECK(f.from_device(dy) == f.matvec(A, x));
+        // SparseMatrix on handles: values and column indices in row blocks, the same x, y gathered
+        SparseMatrix<F256::Element> S;
+        S.num_rows = 41; S.num_cols = cols; S.density = 5;
+        for (size_t i = 0; i < S.num_rows * S.density; i++) S.cells.push_back({(i * 29 + i / S.density) % cols, a[100 + i]});
+        auto dS = f.to_device(S, where);
+        DeviceVec dys = f.alloc_device(S.num_rows, layout == 0 ? Placement::Current : Placement::Replicated);
+        f.spmv(dS, S.num_rows, S.num_cols, S.density, dx, dys);
+        CHECK(f.from_device(dys) == f.spmv(S, x));
     }
     set_devices({});
     // BoxedMontyField: limbs gathered once, chain on the device, scattered once

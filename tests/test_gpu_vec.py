@@ -369,3 +369,51 @@ def test_host_calls_chunk_pipeline_equals_whole_batch(cpa, tuning, threads, name
     assert lib.fpgpu_mul(f._h, a2.ctypes.data, b.ctypes.data, a2.ctypes.data, n) == 0
     f.mul_vec(va, vb, vo)
     assert np.array_equal(a2, vo.download())
+
+
+def test_handle_api_from_several_host_threads(cpa):
+    """The reference's configs are Send + Sync and shared between rayon workers (src/lib.rs:62-65): four host
+    threads run chains, folds, inversions and staged copies on their own vectors at the same time (ctypes drops
+    the GIL inside the library), all through one context and one device slot; every thread's results must
+    equal the single-threaded ones."""
+    import threading
+    from oracle.fp_oracle import Oracle
+    f, o = cpa.MontyField(cpa.BN254_FR, 4), Oracle(cpa.BN254_FR, 4)
+    V = cpa.DeviceVector
+    n_small, n_big = 30011, (6 << 20) // 32 + 5        # the big one goes through the staging lanes
+    errors, results = [], {}
+
+    def work(t):
+        try:
+            a, b = V.alloc(f, n_small).fill_random(100 + t), V.alloc(f, n_small).fill_random(200 + t)
+            u, w = V.alloc(f, n_small), V.alloc(f, n_small)
+            for _ in range(5):
+                f.mul_vec(a, b, u)
+                f.add_vec(u, a, w)
+                f.sqr_vec(w, u)
+                s = f.sum_vec(u)
+                flags = f.inv_vec(u, w)
+            big = V.alloc(f, n_big).fill_random(300 + t)
+            h = big.download()
+            back = V.from_host(f, h)
+            dot = f.dot_vec(big, back)
+            host = f.mul(h, h)                          # chunk pipeline, also under the staging mutex
+            results[t] = (a.download(), b.download(), u.download(), w.download(), s, flags, h, dot, host)
+        except Exception as e:                          # noqa: BLE001 - reported below
+            errors.append((t, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    for t, (a, b, u, w, s, flags, h, dot, host) in results.items():
+        want_u = o.sqr(o.add(o.mul(a, b), a))
+        assert np.array_equal(u, want_u), t
+        assert np.array_equal(s, o.sum(want_u)), t
+        want_w, want_flags = o.batch_inv(want_u)
+        assert np.array_equal(w, want_w) and np.array_equal(flags, want_flags), t
+        sq = o.sqr(h[:4096])
+        assert np.array_equal(host[:4096], sq), t
+        assert np.array_equal(dot, f.sum(host)), t      # sum of squares, single-threaded host call
