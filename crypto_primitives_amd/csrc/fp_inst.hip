@@ -249,6 +249,10 @@ hipError_t Launch<N>::pow(const fpgpu_ctx* ctx, const void* a, const uint32_t* e
     PowExp e;
     for (int i = 0; i < 16; i++) e.w[i] = exp32[i];
     e.top = top_bit;
+    int ones = 0;
+    for (int i = 0; i < 16; i++) ones += __builtin_popcount(exp32[i]);
+    const long hook = tuning().pow_window;   // tuning / tests: 0 forces the binary ladder, 1 the windowed one
+    e.windowed = hook >= 0 ? (hook > 0 && top_bit > 0) : ones > kPowWindowMinOnes;
     hipLaunchKernelGGL((k_pow<N>), dim3(grid_for(n)), dim3(kBlock), 0, s, (const uint32_t*)a, (uint32_t*)out, n, e,
                        make_params<N>(ctx));
     return hipSuccess;

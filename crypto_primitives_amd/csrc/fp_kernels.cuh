@@ -700,18 +700,24 @@ __global__ __launch_bounds__(kMMTile* kMMTile) void k_matmul(const uint32_t* __r
 // ---- batched pow with one exponent for the whole batch ---------------
 // SemiringConfig::pow_u32 / FieldConfig::pow (crypto_bigint_monty.rs:163-172,239-249;
 // helpers/crypto_bigint.rs:220-455, a 4-bit-window "almost Montgomery" ladder).  The result
-// is the canonical residue x^e in Montgomery form whatever the ladder, so this uses plain
-// left-to-right square-and-multiply: the exponent is wave-uniform (kernel argument), every
-// branch on its bits is scalar.  x^0 = 1 (also 0^0), as the reference.
+// is the canonical residue x^e in Montgomery form whatever the ladder.  The exponent is
+// wave-uniform (kernel argument), so every decision on its bits is scalar and the waves never
+// diverge: a short or sparse exponent runs plain left-to-right square-and-multiply; a dense one a
+// sliding window of three bits over the odd powers x, x^3, x^5, x^7 held in registers -- one
+// multiplication per window (about bits / 4) instead of one per set bit (bits / 2), for one squaring
+// and three multiplications of set-up.  x^0 = 1 (also 0^0), as the reference.
 struct PowExp {
     uint32_t w[16];  // exponent, 32-bit little-endian limbs
     int top;         // index of its highest set bit, -1 if the exponent is zero
+    int windowed;    // 1: sliding-window ladder (the host decides: more than kPowWindowMinOnes set bits)
 };
+constexpr int kPowWindowMinOnes = 12;
 template <int N>
 __global__ __launch_bounds__(kBlock) void k_pow(const uint32_t* __restrict__ a, uint32_t* __restrict__ out, size_t n,
                                                 const PowExp e, const FpParams<N> P) {
     const size_t stride = (size_t)gridDim.x * kBlock;
     PowLadder<N> ladder(P);   // fp_unsat.cuh: from N = 6 on, unsaturated limbs in the domain of R' = 2^(29 L)
+    auto bit = [&](int b) -> uint32_t { return (e.w[b >> 5] >> (b & 31)) & 1u; };
     for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
         uint32_t w[N];
         if (e.top < 0) {
@@ -720,9 +726,44 @@ __global__ __launch_bounds__(kBlock) void k_pow(const uint32_t* __restrict__ a, 
             load_elem<N>(w, a, i);
             if (e.top > 0) {   // exponent one hands the input back untouched
                 ladder.start(w);
-                for (int b = e.top - 1; b >= 0; b--) {
+                if (!e.windowed) {
+                    for (int b = e.top - 1; b >= 0; b--) {
+                        ladder.square();
+                        if (bit(b)) ladder.mul_base();
+                    }
+                } else {
+                    typename PowLadder<N>::Val x1, x3, x5, x7, y;
+                    ladder.get_acc(x1);
                     ladder.square();
-                    if ((e.w[b >> 5] >> (b & 31)) & 1u) ladder.mul_base();
+                    ladder.get_acc(y);        // x^2
+                    ladder.mul_val(x1);
+                    ladder.get_acc(x3);
+                    ladder.mul_val(y);
+                    ladder.get_acc(x5);
+                    ladder.mul_val(y);
+                    ladder.get_acc(x7);
+                    bool first = true;
+                    for (int b = e.top; b >= 0;) {
+                        if (!bit(b)) {        // never the first step: bit `top` is set
+                            ladder.square();
+                            b--;
+                            continue;
+                        }
+                        int len = b >= 2 ? 3 : b + 1;          // the longest window of <= 3 bits that ends in a one
+                        while (!bit(b - len + 1)) len--;
+                        uint32_t val = 0;
+                        for (int k = 0; k < len; k++) val = 2 * val + bit(b - k);
+                        if (!first)
+                            for (int k = 0; k < len; k++) ladder.square();
+                        // the odd power of this window (a scalar choice: `val` is wave-uniform)
+#pragma unroll
+                        for (int l = 0; l < (int)(sizeof(y) / sizeof(y[0])); l++)
+                            y[l] = val == 1 ? x1[l] : val == 3 ? x3[l] : val == 5 ? x5[l] : x7[l];
+                        if (first) ladder.set_acc(y);
+                        else ladder.mul_val(y);
+                        first = false;
+                        b -= len;
+                    }
                 }
                 ladder.finish(w);
             }

@@ -459,6 +459,22 @@ struct PowLadder<N, false> {
 #pragma unroll
         for (int l = 0; l < N; l++) w[l] = acc[l];
     }
+    // the running value in the ladder's own form (table entries of the windowed ladder)
+    typedef uint32_t Val[N];
+    __device__ __forceinline__ void get_acc(Val& o) const {
+#pragma unroll
+        for (int l = 0; l < N; l++) o[l] = acc[l];
+    }
+    __device__ __forceinline__ void set_acc(const Val& o) {
+#pragma unroll
+        for (int l = 0; l < N; l++) acc[l] = o[l];
+    }
+    __device__ __forceinline__ void mul_val(const Val& y) {
+        uint32_t t[N];
+        mont_mul<N>(t, acc, y, P);
+#pragma unroll
+        for (int l = 0; l < N; l++) acc[l] = t[l];
+    }
 };
 
 template <int N>
@@ -503,6 +519,21 @@ struct PowLadder<N, true> {
         umont_mul<kUB, L>(t, acc, kout, U);
         ucanon<N>(t, U);
         ustore<N>(w, t);
+    }
+    typedef uint32_t Val[L];
+    __device__ __forceinline__ void get_acc(Val& o) const {
+#pragma unroll
+        for (int l = 0; l < L; l++) o[l] = acc[l];
+    }
+    __device__ __forceinline__ void set_acc(const Val& o) {
+#pragma unroll
+        for (int l = 0; l < L; l++) acc[l] = o[l];
+    }
+    __device__ __forceinline__ void mul_val(const Val& y) {
+        uint32_t t[L];
+        umont_mul<kUB, L>(t, acc, y, U);
+#pragma unroll
+        for (int l = 0; l < L; l++) acc[l] = t[l];
     }
 };
 

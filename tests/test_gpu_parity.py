@@ -775,3 +775,27 @@ def test_device_wrappers_validate_shapes(cpa):
         f.mul_dev(a.cpu(), b, a)
     with pytest.raises(ValueError, match="operand length mismatch"):
         f.mul_chain(np.ones((4, 4), dtype=np.uint64), np.ones((3, 4), dtype=np.uint64), 2)
+
+
+@pytest.mark.parametrize("case", _UNSAT_MODULI + [("goldilocks", 2**64 - 2**32 + 1, 1), ("p127", 2**127 - 1, 2)],
+                         ids=lambda c: c[0])
+@pytest.mark.parametrize("window", [0, 1])
+def test_pow_both_ladders_every_width(cpa, tuning, case, window):
+    """The binary ladder (FPGPU_POW_WINDOW=0) and the sliding-window ladder over x, x^3, x^5, x^7 (=1) must both
+    give the oracle's result (the reference's 4-bit-window ladder) at every compiled width, tight and lazy
+    moduli: exponents that exercise every window value and length, runs of zeros and ones, a first window
+    of one, two and three bits, and the exponent's top bit in every position of a word boundary."""
+    from oracle.fp_oracle import Oracle
+    _, p, n64 = case
+    tuning("FPGPU_POW_WINDOW", window)
+    f, o = cpa.MontyField(p, n64), Oracle(p, n64)
+    rnd = random.Random(p % 999983 + window)
+    xs = [0, 1, 2, p - 1, p - 2] + [rnd.randrange(p) for _ in range(200)]
+    x = ints_to_array(xs, n64)
+    bits = 64 * n64
+    exps = [2, 3, 4, 5, 6, 7, 0b1011, 0b1101, 0b1111, 0b10001, 0b100101, 0b1110111, 0xAAAAAAAA, 0x55555555, 0xDB6DB6DB,
+            2**31, 2**32, 2**32 + 1, 2**33 - 1, (1 << bits) - 1, (1 << (bits - 1)) | 1, p - 2, p - 1, p, (p - 1) // 2,
+            rnd.getrandbits(bits), rnd.getrandbits(bits) | (1 << (bits - 1)), rnd.getrandbits(bits - 1), rnd.getrandbits(70)]
+    for e in exps:
+        ebits = max(bits, 64 * ((e.bit_length() + 63) // 64))      # the exponent may be wider than the field
+        assert np.array_equal(f.pow(x, e), o.pow(x, e, exponent_bits=ebits)), hex(e)
