@@ -213,6 +213,7 @@ def main():
         if args.workload != "matvec":
             extra["matvec_bn254"] = bench_matvec(args, f, world, rank, distributed, time_steps, False, samples)
         extra["spmv_bn254"] = bench_spmv(f, rank, time_steps)
+        extra["pow_bn254"] = bench_pow(f, a, out, time_steps)
         if rank == 0:
             extra["drop_in_chain_bn254"] = bench_drop_in_chain(f)
 
@@ -438,6 +439,16 @@ def bench_spmv(f, rank, time_steps):
     bytes_alg = 36.0 * rows * density + 32.0 * (cols + rows)   # value + index per cell, x and y once
     return {"cells_per_s": rows * density / kern, "ms": kern * 1e3, "rows": rows, "density": density,
             "hbm_GBps_per_gpu": bytes_alg / kern / 1e9, "hbm_frac": bytes_alg / kern / 1e9 / HBM_PEAK_GBPS}
+
+
+def bench_pow(f, a, out, time_steps):
+    """Batched pow, one replica per rank: x^(p-2) over 2^22 BN254 elements -- the Fermat
+    inverse, a dense 254-bit exponent: 253 squarings + 67 multiplications on the sliding-window ladder."""
+    n = 1 << 22
+    e = f.modulus_int - 2
+    wall, kern = time_steps(lambda: f.pow_dev(a[:n], e, out[:n]), 3, 1)
+    return {"Gpow_per_s": n / kern / 1e9, "ms": kern * 1e3, "elements": n, "exponent": "p - 2",
+            "Gmul_equiv_per_s_binary_ladder_count": n * (e.bit_length() - 2 + bin(e).count("1")) / kern / 1e9}
 
 
 def bench_drop_in_chain(f):
