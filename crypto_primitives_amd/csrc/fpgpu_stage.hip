@@ -50,8 +50,7 @@ class WorkerPool {
         for (auto& t : threads_) t.join();
     }
     int width() const { return (int)threads_.size() + 1; }
-    void run(int parts, const std::function<void(int)>& fn) {
-        parts = std::min(parts, width());
+    void run(int parts, const std::function<void(int)>& fn) {   // parts <= width(), checked by the caller
         if (parts <= 1) {
             fn(0);
             return;
@@ -149,11 +148,11 @@ int acquire(int lanes, DeviceLanes** out) {
     if (!d) {
         d = new DeviceLanes();
         d->device = dev;
-        HIP_TRY(hipEventCreateWithFlags(&d->order, hipEventDisableTiming));
-        HIP_TRY(hipStreamCreateWithFlags(&d->up, hipStreamNonBlocking));
-        HIP_TRY(hipStreamCreateWithFlags(&d->compute, hipStreamNonBlocking));
-        g_stage.devices.push_back(d);
+        g_stage.devices.push_back(d);   // kept even if a creation below fails: the next call completes it
     }
+    if (!d->order) HIP_TRY(hipEventCreateWithFlags(&d->order, hipEventDisableTiming));
+    if (!d->up) HIP_TRY(hipStreamCreateWithFlags(&d->up, hipStreamNonBlocking));
+    if (!d->compute) HIP_TRY(hipStreamCreateWithFlags(&d->compute, hipStreamNonBlocking));
     for (; g_stage.pinned_lanes < lanes; g_stage.pinned_lanes++)
         for (int s = 0; s < 2; s++)
             HIP_TRY(hipHostMalloc((void**)&g_stage.pin[g_stage.pinned_lanes][s], kSlotBytes, hipHostMallocPortable));
@@ -202,6 +201,8 @@ struct LaneStatus {
 // stream before it returns so that no DMA is left running on the shared buffers.
 template <typename Body>
 int run_lanes(DeviceLanes* d, int lanes, Body&& body) {
+    if (g_stage.pool->width() < lanes || (int)d->lanes.size() < lanes)   // every lane owns chunks: none may be missing
+        return fail(FPGPU_ERR_HIP, "staging: fewer copy threads than lanes");
     LaneStatus st;
     g_stage.pool->run(lanes, [&](int t) {
         int rc = FPGPU_OK;
