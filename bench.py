@@ -187,7 +187,8 @@ def main():
                            "hbm_frac": bytes_per * n / kern / 1e9 / HBM_PEAK_GBPS}
         # the remaining elementwise rows of SURVEY.md 8a (A4, A8): one read, one write
         for name, fn in (("neg", lambda: f.neg_dev(a, out)), ("to_mont", lambda: f.to_mont_dev(a, out)),
-                         ("from_mont", lambda: f.from_mont_dev(a, out))):
+                         ("from_mont", lambda: f.from_mont_dev(a, out)), ("double", lambda: f.double_dev(a, out)),
+                         ("div_by_2", lambda: f.div_by_2_dev(a, out))):
             wall, kern = time_steps(fn, ksteps, xwarm)
             extra[name] = {"Gelem_per_s": n * world * ksteps / wall / 1e9, "kernel_ms": kern * 1e3,
                            "hbm_GBps_per_gpu": 64 * n / kern / 1e9, "hbm_frac": 64 * n / kern / 1e9 / HBM_PEAK_GBPS}

@@ -27,6 +27,8 @@ SIGNATURES = {
     "fpgpu_add_dev": (_int, [_vp, _vp, _vp, _vp, _sz, _vp]),
     "fpgpu_sub_dev": (_int, [_vp, _vp, _vp, _vp, _sz, _vp]),
     "fpgpu_neg_dev": (_int, [_vp, _vp, _vp, _sz, _vp]),
+    "fpgpu_double_dev": (_int, [_vp, _vp, _vp, _sz, _vp]),
+    "fpgpu_div_by_2_dev": (_int, [_vp, _vp, _vp, _sz, _vp]),
     "fpgpu_to_mont_dev": (_int, [_vp, _vp, _vp, _sz, _vp]),
     "fpgpu_from_mont_dev": (_int, [_vp, _vp, _vp, _sz, _vp]),
     "fpgpu_mul_chain_dev": (_int, [_vp, _vp, _vp, _vp, _sz, _u32, _vp]),
@@ -53,6 +55,8 @@ SIGNATURES = {
     "fpgpu_add": (_int, [_vp, _vp, _vp, _vp, _sz]),
     "fpgpu_sub": (_int, [_vp, _vp, _vp, _vp, _sz]),
     "fpgpu_neg": (_int, [_vp, _vp, _vp, _sz]),
+    "fpgpu_double": (_int, [_vp, _vp, _vp, _sz]),
+    "fpgpu_div_by_2": (_int, [_vp, _vp, _vp, _sz]),
     "fpgpu_to_mont": (_int, [_vp, _vp, _vp, _sz]),
     "fpgpu_from_mont": (_int, [_vp, _vp, _vp, _sz]),
     "fpgpu_mul_chain": (_int, [_vp, _vp, _vp, _vp, _sz, _u32]),
@@ -80,6 +84,8 @@ SIGNATURES = {
     "fpgpu_vec_add": (_int, [_vp, _vp, _vp, _vp]),
     "fpgpu_vec_sub": (_int, [_vp, _vp, _vp, _vp]),
     "fpgpu_vec_neg": (_int, [_vp, _vp, _vp]),
+    "fpgpu_vec_double": (_int, [_vp, _vp, _vp]),
+    "fpgpu_vec_div_by_2": (_int, [_vp, _vp, _vp]),
     "fpgpu_vec_to_mont": (_int, [_vp, _vp, _vp]),
     "fpgpu_vec_from_mont": (_int, [_vp, _vp, _vp]),
     "fpgpu_vec_mul_chain": (_int, [_vp, _vp, _vp, _vp, _u32]),

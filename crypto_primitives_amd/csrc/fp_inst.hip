@@ -45,6 +45,8 @@ hipError_t Launch<N>::elementwise(int op, const fpgpu_ctx* ctx, const void* a, c
         case OP_NEG: launch_ew<N, OP_NEG>(ctx, a, b, out, n, s); break;
         case OP_TO_MONT: launch_ew<N, OP_TO_MONT>(ctx, a, b, out, n, s); break;
         case OP_FROM_MONT: launch_ew<N, OP_FROM_MONT>(ctx, a, b, out, n, s); break;
+        case OP_DOUBLE: launch_ew<N, OP_DOUBLE>(ctx, a, b, out, n, s); break;
+        case OP_HALVE: launch_ew<N, OP_HALVE>(ctx, a, b, out, n, s); break;
         default: return hipErrorInvalidValue;
     }
     return hipSuccess;

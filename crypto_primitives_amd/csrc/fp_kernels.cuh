@@ -61,6 +61,8 @@ __device__ __forceinline__ void elementwise_op(uint32_t (&r)[N], const uint32_t 
     else if constexpr (OP == OP_NEG) mod_neg<N>(r, x, P);
     else if constexpr (OP == OP_TO_MONT) mont_mul_const<N>(r, x, P.r2, P);
     else if constexpr (OP == OP_FROM_MONT) mont_retrieve<N>(r, x, P);
+    else if constexpr (OP == OP_DOUBLE) mod_add<N>(r, x, x, P);
+    else if constexpr (OP == OP_HALVE) mod_half<N>(r, x, P);
 }
 
 // One element per lane per iteration, grid-stride.  (Two elements per lane with both loads issued up

@@ -19,7 +19,7 @@ struct fpgpu_ctx {
 
 namespace fpgpu {
 
-enum Op : int { OP_MUL = 0, OP_SQR = 1, OP_ADD = 2, OP_SUB = 3, OP_NEG = 4, OP_TO_MONT = 5, OP_FROM_MONT = 6 };
+enum Op : int { OP_MUL = 0, OP_SQR = 1, OP_ADD = 2, OP_SUB = 3, OP_NEG = 4, OP_TO_MONT = 5, OP_FROM_MONT = 6, OP_DOUBLE = 7, OP_HALVE = 8 };
 
 #ifndef FPGPU_BLOCK
 #define FPGPU_BLOCK 256

@@ -284,6 +284,12 @@ int fpgpu_to_mont_dev(const fpgpu_ctx* ctx, const void* a, void* out, size_t n, 
 int fpgpu_from_mont_dev(const fpgpu_ctx* ctx, const void* a, void* out, size_t n, void* stream) {
     return elementwise_dev<OP_FROM_MONT>(ctx, a, nullptr, out, n, stream);
 }
+int fpgpu_double_dev(const fpgpu_ctx* ctx, const void* a, void* out, size_t n, void* stream) {
+    return elementwise_dev<OP_DOUBLE>(ctx, a, nullptr, out, n, stream);
+}
+int fpgpu_div_by_2_dev(const fpgpu_ctx* ctx, const void* a, void* out, size_t n, void* stream) {
+    return elementwise_dev<OP_HALVE>(ctx, a, nullptr, out, n, stream);
+}
 
 int fpgpu_mul_chain_dev(const fpgpu_ctx* ctx, const void* a, const void* b, void* out, size_t n, uint32_t iters,
                         void* stream) {
@@ -521,6 +527,14 @@ int fpgpu_to_mont(const fpgpu_ctx* ctx, const uint64_t* a, uint64_t* out, size_t
 int fpgpu_from_mont(const fpgpu_ctx* ctx, const uint64_t* a, uint64_t* out, size_t n) {
     return host_binary(ctx, a, nullptr, out, n, false,
                        [&](void* da, void*, void* dout, size_t cnt, hipStream_t s) { return fpgpu_from_mont_dev(ctx, da, dout, cnt, s); });
+}
+int fpgpu_double(const fpgpu_ctx* ctx, const uint64_t* a, uint64_t* out, size_t n) {
+    return host_binary(ctx, a, nullptr, out, n, false,
+                       [&](void* da, void*, void* dout, size_t cnt, hipStream_t s) { return fpgpu_double_dev(ctx, da, dout, cnt, s); });
+}
+int fpgpu_div_by_2(const fpgpu_ctx* ctx, const uint64_t* a, uint64_t* out, size_t n) {
+    return host_binary(ctx, a, nullptr, out, n, false,
+                       [&](void* da, void*, void* dout, size_t cnt, hipStream_t s) { return fpgpu_div_by_2_dev(ctx, da, dout, cnt, s); });
 }
 int fpgpu_mul_chain(const fpgpu_ctx* ctx, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n,
                     uint32_t iters) {

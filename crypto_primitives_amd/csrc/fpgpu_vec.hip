@@ -699,6 +699,8 @@ int fpgpu_vec_sub(const fpgpu_ctx* ctx, const fpgpu_vec* a, const fpgpu_vec* b, 
 }
 int fpgpu_vec_sqr(const fpgpu_ctx* ctx, const fpgpu_vec* a, fpgpu_vec* out) { return vec_unary(fpgpu_sqr_dev, ctx, a, out); }
 int fpgpu_vec_neg(const fpgpu_ctx* ctx, const fpgpu_vec* a, fpgpu_vec* out) { return vec_unary(fpgpu_neg_dev, ctx, a, out); }
+int fpgpu_vec_double(const fpgpu_ctx* ctx, const fpgpu_vec* a, fpgpu_vec* out) { return vec_unary(fpgpu_double_dev, ctx, a, out); }
+int fpgpu_vec_div_by_2(const fpgpu_ctx* ctx, const fpgpu_vec* a, fpgpu_vec* out) { return vec_unary(fpgpu_div_by_2_dev, ctx, a, out); }
 int fpgpu_vec_to_mont(const fpgpu_ctx* ctx, const fpgpu_vec* a, fpgpu_vec* out) {
     return vec_unary(fpgpu_to_mont_dev, ctx, a, out);
 }

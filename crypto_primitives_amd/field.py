@@ -94,6 +94,8 @@ class MontyField:
     def sub(self, a, b): return self._bin(self._lib.fpgpu_sub, a, b)
     def sqr(self, a): return self._un(self._lib.fpgpu_sqr, a)
     def neg(self, a): return self._un(self._lib.fpgpu_neg, a)
+    def double(self, a): return self._un(self._lib.fpgpu_double, a)      # ConstMontyField::double, const_monty.rs:86-89
+    def div_by_2(self, a): return self._un(self._lib.fpgpu_div_by_2, a)  # ConstMontyField::div_by_2, const_monty.rs:81-84
     def project(self, a): return self._un(self._lib.fpgpu_to_mont, a)    # integers -> Montgomery form
     def lift(self, a): return self._un(self._lib.fpgpu_from_mont, a)     # Montgomery form -> integers
 
@@ -183,6 +185,8 @@ class MontyField:
     def sub_vec(self, a, b, out): return self._v3(self._lib.fpgpu_vec_sub, a, b, out)
     def sqr_vec(self, a, out): return self._v2(self._lib.fpgpu_vec_sqr, a, out)
     def neg_vec(self, a, out): return self._v2(self._lib.fpgpu_vec_neg, a, out)
+    def double_vec(self, a, out): return self._v2(self._lib.fpgpu_vec_double, a, out)
+    def div_by_2_vec(self, a, out): return self._v2(self._lib.fpgpu_vec_div_by_2, a, out)
     def project_vec(self, a, out): return self._v2(self._lib.fpgpu_vec_to_mont, a, out)
     def lift_vec(self, a, out): return self._v2(self._lib.fpgpu_vec_from_mont, a, out)
 
@@ -295,6 +299,8 @@ class MontyField:
     def sub_dev(self, a, b, out): return self._bin_dev(self._lib.fpgpu_sub_dev, a, b, out)
     def sqr_dev(self, a, out): return self._un_dev(self._lib.fpgpu_sqr_dev, a, out)
     def neg_dev(self, a, out): return self._un_dev(self._lib.fpgpu_neg_dev, a, out)
+    def double_dev(self, a, out): return self._un_dev(self._lib.fpgpu_double_dev, a, out)
+    def div_by_2_dev(self, a, out): return self._un_dev(self._lib.fpgpu_div_by_2_dev, a, out)
     def to_mont_dev(self, a, out): return self._un_dev(self._lib.fpgpu_to_mont_dev, a, out)
     def from_mont_dev(self, a, out): return self._un_dev(self._lib.fpgpu_from_mont_dev, a, out)
 

@@ -254,6 +254,8 @@ struct DeviceOps {
     void add(const DeviceVec& a, const DeviceVec& b, DeviceVec& out) const { fpgpu_check(fpgpu_vec_add(ctx, a.raw(), b.raw(), out.raw())); }
     void sub(const DeviceVec& a, const DeviceVec& b, DeviceVec& out) const { fpgpu_check(fpgpu_vec_sub(ctx, a.raw(), b.raw(), out.raw())); }
     void neg(const DeviceVec& a, DeviceVec& out) const { fpgpu_check(fpgpu_vec_neg(ctx, a.raw(), out.raw())); }
+    void dbl(const DeviceVec& a, DeviceVec& out) const { fpgpu_check(fpgpu_vec_double(ctx, a.raw(), out.raw())); }
+    void div_by_2(const DeviceVec& a, DeviceVec& out) const { fpgpu_check(fpgpu_vec_div_by_2(ctx, a.raw(), out.raw())); }
     void square(const DeviceVec& a, DeviceVec& out) const { fpgpu_check(fpgpu_vec_sqr(ctx, a.raw(), out.raw())); }
     void project(const DeviceVec& a, DeviceVec& out) const { fpgpu_check(fpgpu_vec_to_mont(ctx, a.raw(), out.raw())); }
     void lift(const DeviceVec& a, DeviceVec& out) const { fpgpu_check(fpgpu_vec_from_mont(ctx, a.raw(), out.raw())); }
@@ -416,6 +418,9 @@ class MontyField {
     void sub_batch(const Element* a, const Element* b, Element* out, size_t n) const { fpgpu_check(fpgpu_sub(ctx_.get(), p(a), p(b), p(out), n)); }
     void neg_batch(const Element* a, Element* out, size_t n) const { fpgpu_check(fpgpu_neg(ctx_.get(), p(a), p(out), n)); }
     void square_batch(const Element* a, Element* out, size_t n) const { fpgpu_check(fpgpu_sqr(ctx_.get(), p(a), p(out), n)); }
+    // ConstMontyField::double / div_by_2 (crypto_bigint_const_monty.rs:81-89)
+    void double_batch(const Element* a, Element* out, size_t n) const { fpgpu_check(fpgpu_double(ctx_.get(), p(a), p(out), n)); }
+    void div_by_2_batch(const Element* a, Element* out, size_t n) const { fpgpu_check(fpgpu_div_by_2(ctx_.get(), p(a), p(out), n)); }
     void project_batch(const Integer* a, Element* out, size_t n) const { fpgpu_check(fpgpu_to_mont(ctx_.get(), a[0].words.data(), p(out), n)); }
     void lift_batch(const Element* a, Integer* out, size_t n) const { fpgpu_check(fpgpu_from_mont(ctx_.get(), p(a), out[0].words.data(), n)); }
     // pow with one exponent for the whole batch (FieldConfig::pow, crypto_bigint_monty.rs:239-249)
@@ -502,6 +507,8 @@ class MontyField {
     void sub_batch(const DeviceVec& a, const DeviceVec& b, DeviceVec& out) const { on_device().sub(a, b, out); }
     void neg_batch(const DeviceVec& a, DeviceVec& out) const { on_device().neg(a, out); }
     void square_batch(const DeviceVec& a, DeviceVec& out) const { on_device().square(a, out); }
+    void double_batch(const DeviceVec& a, DeviceVec& out) const { on_device().dbl(a, out); }
+    void div_by_2_batch(const DeviceVec& a, DeviceVec& out) const { on_device().div_by_2(a, out); }
     void pow_batch(const DeviceVec& a, const Integer& e, DeviceVec& out) const { on_device().pow(a, e.words.data(), (uint32_t)LIMBS, out); }
     std::vector<uint8_t> inv_batch(const DeviceVec& x, DeviceVec& out) const { return on_device().inv(x, out); }
     Element sum_batch(const DeviceVec& v) const { Element r; fpgpu_check(fpgpu_vec_sum(ctx_.get(), v.raw(), p(&r))); return r; }
@@ -682,7 +689,24 @@ class ConstMontyField {
     ConstMontyField& operator-=(const ConstMontyField& o) { return *this = *this - o; }
     ConstMontyField& operator*=(const ConstMontyField& o) { return *this = *this * o; }
     ConstMontyField square() const { return *this * *this; }
-    ConstMontyField dbl() const { return *this + *this; }
+    ConstMontyField dbl() const { return *this + *this; }   // `double` (crypto_bigint_const_monty.rs:86-89)
+    // the x with x + x = self (crypto_bigint_const_monty.rs:81-84): halve the Montgomery representative mod p
+    ConstMontyField div_by_2() const {
+        const Uint<LIMBS> m = config().modulus();
+        Uint<LIMBS> t = e_.v;
+        uint64_t carry = 0;
+        if (t.words[0] & 1) {
+            for (size_t i = 0; i < LIMBS; i++) {
+                unsigned __int128 s = (unsigned __int128)t.words[i] + m.words[i] + carry;
+                t.words[i] = (uint64_t)s;
+                carry = (uint64_t)(s >> 64);
+            }
+        }
+        for (size_t i = 0; i < LIMBS; i++) t.words[i] = (t.words[i] >> 1) | ((i + 1 < LIMBS ? t.words[i + 1] : carry) << 63);
+        MontyFieldElement<LIMBS> r;
+        r.v = t;
+        return ConstMontyField(r);
+    }
     std::optional<ConstMontyField> inv() const {
         auto i = config().inv(e_);
         if (!i) return std::nullopt;
@@ -703,6 +727,8 @@ class ConstMontyField {
     static void square_batch(const ConstMontyField* a, ConstMontyField* out, size_t n) {
         config().square_batch(&a->e_, &out->e_, n);
     }
+    static void double_batch(const ConstMontyField* a, ConstMontyField* out, size_t n) { config().double_batch(&a->e_, &out->e_, n); }
+    static void div_by_2_batch(const ConstMontyField* a, ConstMontyField* out, size_t n) { config().div_by_2_batch(&a->e_, &out->e_, n); }
 
    private:
     MontyFieldElement<LIMBS> e_;

@@ -102,6 +102,11 @@ int fpgpu_to_mont_dev(const fpgpu_ctx *ctx, const void *a, void *out, size_t n, 
 /* lift: Montgomery form -> canonical integer = monty_retrieve_inner
  * (crypto_bigint_monty.rs:369-385, src/helpers/crypto_bigint.rs:13-37). */
 int fpgpu_from_mont_dev(const fpgpu_ctx *ctx, const void *a, void *out, size_t n, void *stream);
+/* ConstMontyField::double (crypto_bigint_const_monty.rs:86-89): a + a mod p. */
+int fpgpu_double_dev(const fpgpu_ctx *ctx, const void *a, void *out, size_t n, void *stream);
+/* ConstMontyField::div_by_2 (crypto_bigint_const_monty.rs:81-84): the x with x + x = a, i.e. a / 2 for even
+ * a and (a + p) / 2 for odd a (on the Montgomery representative, which halves the value it stands for). */
+int fpgpu_div_by_2_dev(const fpgpu_ctx *ctx, const void *a, void *out, size_t n, void *stream);
 /* "Mul assign" bench shape (benches/field_ops_bench_common.rs:27-39), batched:
  * acc[i] = a[i]; repeat `iters` times acc[i] = mul(acc[i], b[i]); out[i] = acc[i]. */
 int fpgpu_mul_chain_dev(const fpgpu_ctx *ctx, const void *a, const void *b, void *out, size_t n,
@@ -200,6 +205,8 @@ int fpgpu_sub(const fpgpu_ctx *ctx, const uint64_t *a, const uint64_t *b, uint64
 int fpgpu_neg(const fpgpu_ctx *ctx, const uint64_t *a, uint64_t *out, size_t n);
 int fpgpu_to_mont(const fpgpu_ctx *ctx, const uint64_t *a, uint64_t *out, size_t n);
 int fpgpu_from_mont(const fpgpu_ctx *ctx, const uint64_t *a, uint64_t *out, size_t n);
+int fpgpu_double(const fpgpu_ctx *ctx, const uint64_t *a, uint64_t *out, size_t n);
+int fpgpu_div_by_2(const fpgpu_ctx *ctx, const uint64_t *a, uint64_t *out, size_t n);
 int fpgpu_mul_chain(const fpgpu_ctx *ctx, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t n,
                     uint32_t iters);
 int fpgpu_pow(const fpgpu_ctx *ctx, const uint64_t *a, const uint64_t *exponent_le, uint32_t exponent_words,
@@ -277,6 +284,8 @@ int fpgpu_vec_sub(const fpgpu_ctx *ctx, const fpgpu_vec *a, const fpgpu_vec *b, 
 int fpgpu_vec_neg(const fpgpu_ctx *ctx, const fpgpu_vec *a, fpgpu_vec *out);
 int fpgpu_vec_to_mont(const fpgpu_ctx *ctx, const fpgpu_vec *a, fpgpu_vec *out);
 int fpgpu_vec_from_mont(const fpgpu_ctx *ctx, const fpgpu_vec *a, fpgpu_vec *out);
+int fpgpu_vec_double(const fpgpu_ctx *ctx, const fpgpu_vec *a, fpgpu_vec *out);
+int fpgpu_vec_div_by_2(const fpgpu_ctx *ctx, const fpgpu_vec *a, fpgpu_vec *out);
 int fpgpu_vec_mul_chain(const fpgpu_ctx *ctx, const fpgpu_vec *a, const fpgpu_vec *b, fpgpu_vec *out, uint32_t iters);
 int fpgpu_vec_pow(const fpgpu_ctx *ctx, const fpgpu_vec *a, const uint64_t *exponent_le, uint32_t exponent_words,
                   fpgpu_vec *out);

@@ -402,7 +402,30 @@ void fpo_lift(const word *x, const word *modulus, word mod_neg_inv, word *out, s
  * batch compositions.
  * op codes match include/fpgpu.h's kernels one-to-one for the tests. */
 enum { FPO_MUL = 0, FPO_SQR = 1, FPO_ADD = 2, FPO_SUB = 3, FPO_NEG = 4,
-       FPO_TO_MONT = 5, FPO_FROM_MONT = 6, FPO_MUL_BOXED = 7 };
+       FPO_TO_MONT = 5, FPO_FROM_MONT = 6, FPO_MUL_BOXED = 7, FPO_DOUBLE = 8, FPO_DIV_BY_2 = 9 };
+
+/* ConstMontyField::div_by_2 (src/field/crypto_bigint_const_monty.rs:81-84) hands the Montgomery
+ * representative to crypto-bigint's ConstMontyForm::div_by_2 (third-party, >= 0.7.1 < 0.8, not under
+ * /root/reference; published algorithm, modular/div_by_2.rs): (half, is_odd) = a.shr1_with_carry();
+ * if_odd = half + (p >> 1) + 1 (wrapping); result = is_odd ? if_odd : half.  For a < p that is the
+ * canonical x with x + x = a (mod p); the reference pins it with `half + half == even`
+ * (crypto_bigint_const_monty.rs:1184-1187). */
+static void fpo_div_by_2(const word *a, const word *p, word *out, size_t n)
+{
+    word half[FPO_MAX_LIMBS], hp[FPO_MAX_LIMBS];
+    const int odd = (int)(a[0] & 1);
+    for (size_t i = 0; i < n; i++) {
+        half[i] = (a[i] >> 1) | (i + 1 < n ? a[i + 1] << 63 : 0);
+        hp[i] = (p[i] >> 1) | (i + 1 < n ? p[i + 1] << 63 : 0);
+    }
+    if (!odd) { memcpy(out, half, n * sizeof(word)); return; }
+    unsigned __int128 c = 1;                       /* + Uint::ONE */
+    for (size_t i = 0; i < n; i++) {
+        c += (unsigned __int128)half[i] + hp[i];
+        out[i] = (word)c;                          /* wrapping_add */
+        c >>= 64;
+    }
+}
 
 int fpo_batch_op(int op, const word *modulus, size_t n, const word *a, const word *b,
                  word *out, size_t count, int threads)
@@ -428,6 +451,9 @@ int fpo_batch_op(int op, const word *modulus, size_t n, const word *a, const wor
         case FPO_TO_MONT:   fpo_project(ai, modulus, r2, tmp, n); break;
         case FPO_FROM_MONT: fpo_lift(ai, modulus, inv, tmp, n); break;
         case FPO_MUL_BOXED: fpo_boxed_mul(ai, bi, modulus, inv, tmp, n); break;
+        /* ConstMontyField::double (crypto_bigint_const_monty.rs:86-89) -> ConstMontyForm::double = add_mod(a, a) */
+        case FPO_DOUBLE:    fpo_add_mod(ai, ai, modulus, tmp, n); break;
+        case FPO_DIV_BY_2:  fpo_div_by_2(ai, modulus, tmp, n); break;
         default: memset(tmp, 0, sizeof tmp); break;
         }
         memcpy(oi, tmp, n * sizeof(word));

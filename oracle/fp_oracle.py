@@ -14,7 +14,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "libfp_oracle.so")
 
-MUL, SQR, ADD, SUB, NEG, TO_MONT, FROM_MONT, MUL_BOXED = range(8)
+MUL, SQR, ADD, SUB, NEG, TO_MONT, FROM_MONT, MUL_BOXED, DOUBLE, DIV_BY_2 = range(10)
 
 
 def build(force=False):
@@ -104,6 +104,8 @@ class Oracle:
     def add(self, a, b, threads=1): return self.batch(ADD, a, b, threads)
     def sub(self, a, b, threads=1): return self.batch(SUB, a, b, threads)
     def neg(self, a, threads=1): return self.batch(NEG, a, None, threads)
+    def double(self, a, threads=1): return self.batch(DOUBLE, a, None, threads)
+    def div_by_2(self, a, threads=1): return self.batch(DIV_BY_2, a, None, threads)
     def to_mont(self, a, threads=1): return self.batch(TO_MONT, a, None, threads)
     def from_mont(self, a, threads=1): return self.batch(FROM_MONT, a, None, threads)
 

@@ -143,6 +143,14 @@ pub trait BatchFieldConfig: GpuMarshal {
     fn square_batch(&self, a: &[Self::Element]) -> Result<Vec<Self::Element>, GpuError> {
         unary(self, a, sys::fpgpu_sqr)
     }
+    /// `ConstMontyField::double` (crypto_bigint_const_monty.rs:86-89).
+    fn double_batch(&self, a: &[Self::Element]) -> Result<Vec<Self::Element>, GpuError> {
+        unary(self, a, sys::fpgpu_double)
+    }
+    /// `ConstMontyField::div_by_2` (crypto_bigint_const_monty.rs:81-84): the `x` with `x + x = a`.
+    fn div_by_2_batch(&self, a: &[Self::Element]) -> Result<Vec<Self::Element>, GpuError> {
+        unary(self, a, sys::fpgpu_div_by_2)
+    }
     /// `inv` (src/field.rs:152): `None` exactly where the scalar method returns `None`.
     fn inv_batch(&self, x: &[Self::Element]) -> Result<Vec<Option<Self::Element>>, GpuError> {
         let ctx = self.gpu_ctx()?;
@@ -370,6 +378,12 @@ pub trait DeviceBatchFieldConfig: GpuMarshal {
     }
     fn square_dev(&self, ctx: &GpuCtx, a: &DeviceVec, out: &mut DeviceVec) -> Result<(), GpuError> {
         vunary(ctx, a, out, sys::fpgpu_vec_sqr)
+    }
+    fn double_dev(&self, ctx: &GpuCtx, a: &DeviceVec, out: &mut DeviceVec) -> Result<(), GpuError> {
+        vunary(ctx, a, out, sys::fpgpu_vec_double)
+    }
+    fn div_by_2_dev(&self, ctx: &GpuCtx, a: &DeviceVec, out: &mut DeviceVec) -> Result<(), GpuError> {
+        vunary(ctx, a, out, sys::fpgpu_vec_div_by_2)
     }
     /// `pow` with one exponent for the whole vector.
     fn pow_dev(&self, ctx: &GpuCtx, a: &DeviceVec, e: &Self::Integer, out: &mut DeviceVec) -> Result<(), GpuError> {

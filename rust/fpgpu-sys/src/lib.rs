@@ -58,6 +58,8 @@ extern "C" {
     pub fn fpgpu_sub_dev(ctx: *const fpgpu_ctx, a: *const c_void, b: *const c_void, out: *mut c_void, n: usize,
                          stream: *mut c_void) -> c_int;
     pub fn fpgpu_neg_dev(ctx: *const fpgpu_ctx, a: *const c_void, out: *mut c_void, n: usize, stream: *mut c_void) -> c_int;
+    pub fn fpgpu_double_dev(ctx: *const fpgpu_ctx, a: *const c_void, out: *mut c_void, n: usize, stream: *mut c_void) -> c_int;
+    pub fn fpgpu_div_by_2_dev(ctx: *const fpgpu_ctx, a: *const c_void, out: *mut c_void, n: usize, stream: *mut c_void) -> c_int;
     pub fn fpgpu_to_mont_dev(ctx: *const fpgpu_ctx, a: *const c_void, out: *mut c_void, n: usize, stream: *mut c_void) -> c_int;
     pub fn fpgpu_from_mont_dev(ctx: *const fpgpu_ctx, a: *const c_void, out: *mut c_void, n: usize, stream: *mut c_void) -> c_int;
     pub fn fpgpu_mul_chain_dev(ctx: *const fpgpu_ctx, a: *const c_void, b: *const c_void, out: *mut c_void, n: usize,
@@ -104,6 +106,8 @@ extern "C" {
     pub fn fpgpu_add(ctx: *const fpgpu_ctx, a: *const u64, b: *const u64, out: *mut u64, n: usize) -> c_int;
     pub fn fpgpu_sub(ctx: *const fpgpu_ctx, a: *const u64, b: *const u64, out: *mut u64, n: usize) -> c_int;
     pub fn fpgpu_neg(ctx: *const fpgpu_ctx, a: *const u64, out: *mut u64, n: usize) -> c_int;
+    pub fn fpgpu_double(ctx: *const fpgpu_ctx, a: *const u64, out: *mut u64, n: usize) -> c_int;
+    pub fn fpgpu_div_by_2(ctx: *const fpgpu_ctx, a: *const u64, out: *mut u64, n: usize) -> c_int;
     pub fn fpgpu_to_mont(ctx: *const fpgpu_ctx, a: *const u64, out: *mut u64, n: usize) -> c_int;
     pub fn fpgpu_from_mont(ctx: *const fpgpu_ctx, a: *const u64, out: *mut u64, n: usize) -> c_int;
     pub fn fpgpu_mul_chain(ctx: *const fpgpu_ctx, a: *const u64, b: *const u64, out: *mut u64, n: usize, iters: u32) -> c_int;
@@ -139,6 +143,8 @@ extern "C" {
     pub fn fpgpu_vec_add(ctx: *const fpgpu_ctx, a: *const fpgpu_vec, b: *const fpgpu_vec, out: *mut fpgpu_vec) -> c_int;
     pub fn fpgpu_vec_sub(ctx: *const fpgpu_ctx, a: *const fpgpu_vec, b: *const fpgpu_vec, out: *mut fpgpu_vec) -> c_int;
     pub fn fpgpu_vec_neg(ctx: *const fpgpu_ctx, a: *const fpgpu_vec, out: *mut fpgpu_vec) -> c_int;
+    pub fn fpgpu_vec_double(ctx: *const fpgpu_ctx, a: *const fpgpu_vec, out: *mut fpgpu_vec) -> c_int;
+    pub fn fpgpu_vec_div_by_2(ctx: *const fpgpu_ctx, a: *const fpgpu_vec, out: *mut fpgpu_vec) -> c_int;
     pub fn fpgpu_vec_to_mont(ctx: *const fpgpu_ctx, a: *const fpgpu_vec, out: *mut fpgpu_vec) -> c_int;
     pub fn fpgpu_vec_from_mont(ctx: *const fpgpu_ctx, a: *const fpgpu_vec, out: *mut fpgpu_vec) -> c_int;
     pub fn fpgpu_vec_mul_chain(ctx: *const fpgpu_ctx, a: *const fpgpu_vec, b: *const fpgpu_vec, out: *mut fpgpu_vec,

@@ -125,6 +125,11 @@ static void test_const_monty_element_style() {  // crypto_bigint_const_monty.rs:
     CHECK(-a + a == E::zero());
     CHECK(a.square() == E::from(100));
     CHECK(a.dbl() == E::from(20));
+    {   // field_methods (crypto_bigint_const_monty.rs:1184-1187) and an odd representative
+        E even = E::from(20), half = even.div_by_2();
+        CHECK(half + half == even);
+        for (int v = 1; v < 40; v++) { E h = E::from(v).div_by_2(); CHECK(h + h == E::from(v)); }
+    }
     CHECK(!E::zero().inv().has_value());
     CHECK(E::from(-1) + E::one() == E::zero());
     CHECK(E::from(7).retrieve() == Uint<4>::from_u64(7));
@@ -240,6 +245,11 @@ static void test_gpu_batches() {
     for (int i = 0; i < 100; i++) { ea[i] = E::from(1000003 * (i + 1)); eb[i] = E::from(-(int64_t)(77 * i + 1)); }
     E::mul_batch(ea.data(), eb.data(), eo.data(), 100);
     for (int i = 0; i < 100; i++) CHECK(eo[i] == ea[i] * eb[i]);
+    // double / div_by_2 (crypto_bigint_const_monty.rs:81-89, checked there as half + half == even, :1184-1187)
+    E::double_batch(ea.data(), eo.data(), 100);
+    for (int i = 0; i < 100; i++) CHECK(eo[i] == ea[i].dbl());
+    E::div_by_2_batch(eb.data(), eo.data(), 100);
+    for (int i = 0; i < 100; i++) CHECK(eo[i] == eb[i].div_by_2() && eo[i] + eo[i] == eb[i]);
     // boxed: gather / scatter
     std::vector<uint64_t> m = {0xb9feffffffffaaabull, 0x1eabfffeb153ffffull, 0x6730d2a0f6b0f624ull,
                                0x64774b84f38512bfull, 0x4b1ba7b6434bacd7ull, 0x1a0111ea397fe69aull};

@@ -695,6 +695,13 @@ def test_every_width_elementwise_fold_matvec_spmv(cpa, case):
         assert np.array_equal(f.add(a, b), o.add(a, b))
         assert np.array_equal(f.sub(a, b), o.sub(a, b))
         assert np.array_equal(f.neg(a), o.neg(a))
+        # double / div_by_2 (const_monty.rs:81-89): against the oracle, against Python ints on the
+        # representatives, and half + half == a (the reference's own check, const_monty.rs:1184-1187)
+        inv2 = pow(2, -1, p)
+        assert np.array_equal(f.double(a), o.double(a)) and array_to_ints(f.double(a)) == [2 * v % p for v in xs]
+        half = f.div_by_2(a)
+        assert np.array_equal(half, o.div_by_2(a)) and array_to_ints(half) == [v * inv2 % p for v in xs]
+        assert np.array_equal(f.add(half, half), a)
         assert np.array_equal(f.lift(a), o.from_mont(a))
         assert np.array_equal(f.sum(a), o.sum(a))
         assert np.array_equal(f.dot(a, b), o.sum(o.mul(a, b)))

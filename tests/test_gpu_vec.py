@@ -352,7 +352,8 @@ def test_host_calls_chunk_pipeline_equals_whole_batch(cpa, tuning, threads, name
     for host, vec, orc, binary in ((f.mul, f.mul_vec, o.mul, True), (f.add, f.add_vec, o.add, True),
                                    (f.sub, f.sub_vec, o.sub, True), (f.sqr, f.sqr_vec, o.sqr, False),
                                    (f.neg, f.neg_vec, o.neg, False), (f.project, f.project_vec, o.to_mont, False),
-                                   (f.lift, f.lift_vec, o.from_mont, False)):
+                                   (f.lift, f.lift_vec, o.from_mont, False), (f.double, f.double_vec, o.double, False),
+                                   (f.div_by_2, f.div_by_2_vec, o.div_by_2, False)):
         got = host(a, b) if binary else host(a)
         (vec(va, vb, vo) if binary else vec(va, vo))
         assert np.array_equal(got, vo.download()), host.__name__
@@ -417,3 +418,32 @@ def test_handle_api_from_several_host_threads(cpa):
         sq = o.sqr(h[:4096])
         assert np.array_equal(host[:4096], sq), t
         assert np.array_equal(dot, f.sum(host)), t      # sum of squares, single-threaded host call
+
+
+@pytest.mark.parametrize("ids", LISTS, ids=["unset", "list1", "list3same"])
+def test_double_and_div_by_2_on_handles_and_device_pointers(cpa, devices, ids):
+    """ConstMontyField::double / div_by_2 (crypto_bigint_const_monty.rs:81-89) through the handle and *_dev layers:
+    oracle parity and the reference's own law half + half == a, on every layout."""
+    import torch
+    from oracle.fp_oracle import Oracle
+    devices(ids)
+    for p, n64, n in ((cpa.BN254_FR, 4, 10007), (cpa.GOLDILOCKS, 1, 4099), (2**192 - 2**64 - 1, 3, 777)):
+        f, o = cpa.MontyField(p, n64), Oracle(p, n64)
+        where = cpa.PLACE_CURRENT if ids is None else cpa.PLACE_SHARDED
+        V = cpa.DeviceVector
+        a = V.alloc(f, n, where).fill_random(31)
+        a.upload(ints_to_array([0, 1, p - 1, p - 2, 2], n64), first=0)
+        ha = a.download()
+        d, h, s = V.alloc(f, n, where), V.alloc(f, n, where), V.alloc(f, n, where)
+        f.double_vec(a, d)
+        f.div_by_2_vec(a, h)
+        f.add_vec(h, h, s)
+        assert np.array_equal(d.download(), o.double(ha))
+        assert np.array_equal(h.download(), o.div_by_2(ha))
+        assert np.array_equal(s.download(), ha)
+        ta = torch.from_numpy(ha.view(np.int64)).cuda()
+        td, th = f.alloc(n), f.alloc(n)
+        f.double_dev(ta, td)
+        f.div_by_2_dev(ta, th)
+        assert np.array_equal(td.cpu().numpy().view(np.uint64), o.double(ha))
+        assert np.array_equal(th.cpu().numpy().view(np.uint64), o.div_by_2(ha))

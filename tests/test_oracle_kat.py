@@ -236,3 +236,26 @@ def test_pow_random_against_definition():
         for e in [0, 1, 2, 15, 16, 17, 255, 2**31, p - 2, p - 1, rnd.getrandbits(64 * n64)]:
             out = array_to_ints(g.o.pow(g.o.to_mont(ints_to_array(xs, n64)), e))
             assert [g.lift(v) for v in out] == [pow(x, e, p) for x in xs]
+
+
+def test_double_and_div_by_2_match_python_ints_and_reference_check():
+    """ConstMontyField::double / div_by_2 (crypto_bigint_const_monty.rs:81-89) in the oracle: on the Montgomery
+    representatives m they are 2m mod p and m/2 mod p; the reference's own check is `half + half == even` for 20
+    and `double(a) == a + a` for 10 (:1177-1187)."""
+    import random
+    from oracle.fp_oracle import Oracle
+    for p, n64 in ((0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001, 4), (2**64 - 2**32 + 1, 1),
+                   (2**256 - 2**32 - 977, 4), (2**512 - 569, 8),
+                   (0x1A0111EA397FE69A4B1BA7B6434BACD764774B84F38512BF6730D2A0F6B0F6241EABFFFEB153FFFFB9FEFFFFFFFFAAAB, 6)):
+        o = Oracle(p, n64)
+        rnd = random.Random(n64)
+        xs = [0, 1, 2, 3, p - 1, p - 2, p >> 1, (p >> 1) + 1] + [rnd.randrange(p) for _ in range(200)]
+        a = ints_to_array(xs, n64)
+        inv2 = pow(2, -1, p)
+        assert array_to_ints(o.double(a)) == [2 * v % p for v in xs]
+        half = o.div_by_2(a)
+        assert array_to_ints(half) == [v * inv2 % p for v in xs]
+        assert np.array_equal(o.add(half, half), a)
+        ten, twenty = o.to_mont(ints_to_array([10], n64)), o.to_mont(ints_to_array([20], n64))
+        assert np.array_equal(o.double(ten), o.add(ten, ten)) and np.array_equal(o.double(ten), twenty)
+        assert np.array_equal(o.div_by_2(twenty), ten)
