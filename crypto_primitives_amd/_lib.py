@@ -34,6 +34,7 @@ SIGNATURES = {
     "fpgpu_mul_chain_dev": (_int, [_vp, _vp, _vp, _vp, _sz, _u32, _vp]),
     "fpgpu_batch_inv_workspace_bytes": (_sz, [_vp, _sz]),
     "fpgpu_batch_inv_dev": (_int, [_vp, _vp, _vp, _vp, _sz, _vp, _sz, _vp]),
+    "fpgpu_div_dev": (_int, [_vp, _vp, _vp, _vp, _vp, _sz, _vp, _sz, _vp]),
     "fpgpu_static_scratch_bytes": (_sz, []),
     "fpgpu_batch_inv_static_dev": (_int, [_vp, _vp, _vp, _vp, _sz, _vp]),
     "fpgpu_matvec_workspace_bytes": (_sz, [_vp, _sz, _sz]),
@@ -61,6 +62,7 @@ SIGNATURES = {
     "fpgpu_from_mont": (_int, [_vp, _vp, _vp, _sz]),
     "fpgpu_mul_chain": (_int, [_vp, _vp, _vp, _vp, _sz, _u32]),
     "fpgpu_batch_inv": (_int, [_vp, _vp, _vp, _vp, _sz]),
+    "fpgpu_div": (_int, [_vp, _vp, _vp, _vp, _vp, _sz]),
     "fpgpu_matvec": (_int, [_vp, _vp, _sz, _sz, _vp, _vp]),
     "fpgpu_matmul": (_int, [_vp, _vp, _vp, _vp, _sz, _sz, _sz]),
     "fpgpu_dot_dev": (_int, [_vp, _vp, _vp, _sz, _vp, _vp, _sz, _vp]),
@@ -91,6 +93,7 @@ SIGNATURES = {
     "fpgpu_vec_mul_chain": (_int, [_vp, _vp, _vp, _vp, _u32]),
     "fpgpu_vec_pow": (_int, [_vp, _vp, _vp, _u32, _vp]),
     "fpgpu_vec_batch_inv": (_int, [_vp, _vp, _vp, _vp, _c.POINTER(_sz)]),
+    "fpgpu_vec_div": (_int, [_vp, _vp, _vp, _vp, _vp, _c.POINTER(_sz)]),
     "fpgpu_vec_sum": (_int, [_vp, _vp, _vp]),
     "fpgpu_vec_product": (_int, [_vp, _vp, _vp]),
     "fpgpu_vec_dot": (_int, [_vp, _vp, _vp, _vp]),

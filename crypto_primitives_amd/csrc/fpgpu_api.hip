@@ -325,6 +325,16 @@ int fpgpu_batch_inv_dev(const fpgpu_ctx* ctx, const void* x, void* out, uint8_t*
     return FPGPU_OK;
 }
 
+int fpgpu_div_dev(const fpgpu_ctx* ctx, const void* a, const void* b, void* out, uint8_t* zero_flags, size_t n,
+                  void* workspace, size_t workspace_bytes, void* stream) {
+    CHECK(check_common(ctx, n));
+    if (n == 0) return FPGPU_OK;
+    CHECK(check_ptr(ctx, a, "a"));
+    if (a == out) return fail(FPGPU_ERR_SHAPE, "div: out must not alias a");
+    CHECK(fpgpu_batch_inv_dev(ctx, b, out, zero_flags, n, workspace, workspace_bytes, stream));   // out = 1 / b, 0 where None
+    return fpgpu_mul_dev(ctx, a, out, out, n, stream);
+}
+
 size_t fpgpu_static_scratch_bytes(void) { return FPGPU_STATIC_SCRATCH_BYTES; }
 
 int fpgpu_batch_inv_static_dev(const fpgpu_ctx* ctx, const void* x, void* out, uint8_t* zero_flags, size_t n,
@@ -604,6 +614,29 @@ int fpgpu_batch_inv(const fpgpu_ctx* ctx, const uint64_t* x, uint64_t* out, uint
     CHECK(ws.alloc(wsb));
     CHECK(upload_staged(dx.p, x, bytes, nullptr));
     CHECK(fpgpu_batch_inv_dev(ctx, dx.p, dout.p, (uint8_t*)dflags.p, n, ws.p, wsb, nullptr));
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    CHECK(download_staged(out, dout.p, bytes, nullptr));
+    if (zero_flags) CHECK(download_staged(zero_flags, dflags.p, n, nullptr));
+    return FPGPU_OK;
+}
+
+int fpgpu_div(const fpgpu_ctx* ctx, const uint64_t* a, const uint64_t* b, uint64_t* out, uint8_t* zero_flags, size_t n) {
+    CHECK(check_common(ctx, n));
+    if (n == 0) return FPGPU_OK;
+    if (!a || !b || !out) return fail(FPGPU_ERR_SHAPE, "null host pointer");
+    CHECK(require_device());
+    size_t bytes = n * ctx->n64 * 8;
+    size_t wsb = fpgpu_batch_inv_workspace_bytes(ctx, n);
+    DevBuf da, db, dout, dflags, ws;
+    CHECK(da.alloc(bytes));
+    CHECK(db.alloc(bytes));
+    CHECK(dout.alloc(bytes));
+    CHECK(dflags.alloc(n));
+    CHECK(ws.alloc(wsb));
+    CHECK(upload_staged(db.p, b, bytes, nullptr));
+    CHECK(fpgpu_batch_inv_dev(ctx, db.p, dout.p, (uint8_t*)dflags.p, n, ws.p, wsb, nullptr));
+    CHECK(upload_staged(da.p, a, bytes, nullptr));
+    CHECK(fpgpu_mul_dev(ctx, da.p, dout.p, dout.p, n, nullptr));
     HIP_TRY(hipStreamSynchronize(nullptr));
     CHECK(download_staged(out, dout.p, bytes, nullptr));
     if (zero_flags) CHECK(download_staged(zero_flags, dflags.p, n, nullptr));

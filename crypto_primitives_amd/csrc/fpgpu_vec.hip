@@ -742,8 +742,21 @@ int fpgpu_vec_pow(const fpgpu_ctx* ctx, const fpgpu_vec* a, const uint64_t* expo
 }
 
 // ---- batch inversion: every part runs Montgomery's trick on its own range, no collective ----------------
+// out = 1 / x, or a / x when `a` is given (FieldConfig::checked_div = mul(a, inv(x)?), src/field.rs:168-170)
+static int vec_inv_or_div(const fpgpu_ctx* ctx, const fpgpu_vec* a, const fpgpu_vec* x, fpgpu_vec* out,
+                          uint8_t* none_flags_host, size_t* none_count);
 int fpgpu_vec_batch_inv(const fpgpu_ctx* ctx, const fpgpu_vec* x, fpgpu_vec* out, uint8_t* none_flags_host,
                         size_t* none_count) {
+    return vec_inv_or_div(ctx, nullptr, x, out, none_flags_host, none_count);
+}
+int fpgpu_vec_div(const fpgpu_ctx* ctx, const fpgpu_vec* a, const fpgpu_vec* b, fpgpu_vec* out, uint8_t* none_flags_host,
+                  size_t* none_count) {
+    CHECK(check_vec(ctx, a, "a"));
+    if (a == out) return fail(FPGPU_ERR_SHAPE, "div: out must not alias a");
+    return vec_inv_or_div(ctx, a, b, out, none_flags_host, none_count);
+}
+static int vec_inv_or_div(const fpgpu_ctx* ctx, const fpgpu_vec* a, const fpgpu_vec* x, fpgpu_vec* out,
+                          uint8_t* none_flags_host, size_t* none_count) {
     CHECK(check_vec(ctx, x, "x"));
     CHECK(check_vec(ctx, out, "out"));
     if (x == out) return fail(FPGPU_ERR_SHAPE, "batch_inv: out must not alias x");
@@ -758,14 +771,16 @@ int fpgpu_vec_batch_inv(const fpgpu_ctx* ctx, const fpgpu_vec* x, fpgpu_vec* out
     }
     for (size_t pi = 0; pi < out->parts.size(); pi++) {
         const VecPart& o = out->parts[pi];
-        const char* px;
+        const char *px, *pa = nullptr;
         CHECK(operand_ptr(x, out, pi, "x", &px));
+        if (a) CHECK(operand_ptr(a, out, pi, "a", &pa));
         if (o.count == 0) continue;
         HIP_TRY(hipSetDevice(o.slot->device));
         const size_t wsb = (fpgpu_batch_inv_workspace_bytes(ctx, o.count) + 255) & ~(size_t)255;
         CHECK(ensure_scratch(o.slot, wsb + o.count));
         uint8_t* dflags = (uint8_t*)o.slot->scratch + wsb;
         CHECK(fpgpu_batch_inv_dev(ctx, px, o.ptr, dflags, o.count, o.slot->scratch, wsb, o.slot->stream));
+        if (a) CHECK(fpgpu_mul_dev(ctx, pa, o.ptr, o.ptr, o.count, o.slot->stream));   // 0 where there is no inverse
         if (want_flags)  // in stream order: the scratch is not reused before this copy has run
             HIP_TRY(hipMemcpyAsync(flags_host + o.first, dflags, o.count, hipMemcpyDeviceToHost, o.slot->stream));
     }

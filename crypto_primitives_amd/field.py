@@ -137,12 +137,23 @@ class MontyField:
         check(self._lib.fpgpu_batch_inv(self._h, _ptr(x), _ptr(out), _ptr(flags), x.shape[0]))
         return out, flags
 
+    def checked_div(self, a, b):
+        """Batch FieldConfig::checked_div (src/field.rs:168-170): (a / b, flags); flags[i] = 1 where the reference
+        returns None (out[i] = 0 there).  One call: inversion and multiplication on the device."""
+        a, b = _np(a, self.n64), _np(b, self.n64)
+        if a.shape != b.shape:
+            raise ValueError("operand length mismatch")
+        out = np.zeros_like(a)
+        flags = np.zeros(a.shape[0], dtype=np.uint8)
+        check(self._lib.fpgpu_div(self._h, _ptr(a), _ptr(b), _ptr(out), _ptr(flags), a.shape[0]))
+        return out, flags
+
     def div(self, a, b):
         """Batch FieldConfig::div (src/field.rs:155-157): raises on a zero divisor."""
-        invb, flags = self.inv(b)
+        out, flags = self.checked_div(a, b)
         if flags.any():
             raise ZeroDivisionError("Division by zero")
-        return self.mul(a, invb)
+        return out
 
     def matvec(self, A, rows, cols, x):
         A, x = _np(A, self.n64), _np(x, self.n64)
@@ -209,6 +220,14 @@ class MontyField:
         flags = np.zeros(len(x), dtype=np.uint8)
         cnt = ctypes.c_size_t()
         check(self._lib.fpgpu_vec_batch_inv(self._h, x._h, out._h, _ptr(flags), ctypes.byref(cnt)))
+        assert cnt.value == int(flags.sum())
+        return flags
+
+    def div_vec(self, a, b, out):
+        """Batch FieldConfig::checked_div on handles: out = a / b; returns the host flag array (1 = None)."""
+        flags = np.zeros(len(b), dtype=np.uint8)
+        cnt = ctypes.c_size_t()
+        check(self._lib.fpgpu_vec_div(self._h, a._h, b._h, out._h, _ptr(flags), ctypes.byref(cnt)))
         assert cnt.value == int(flags.sum())
         return flags
 
@@ -344,6 +363,15 @@ class MontyField:
         wp, wb = self._chk_bytes(workspace, self.inv_workspace_bytes(n), "workspace")
         check(self._lib.fpgpu_batch_inv_dev(self._h, self._chk_t(x, n, "x"), self._chk_t(out, n, "out"), fp, n, wp, wb,
                                             self._stream()))
+        return out
+
+    def div_dev(self, a, b, out, flags, workspace):
+        """fpgpu_div_dev: out = a / b (checked_div: flags[i] = 1 and out[i] = 0 where b[i] has no inverse)."""
+        n = a.numel() // self.n64
+        fp = self._chk_bytes(flags, n, "flags")[0] if flags is not None else None
+        wp, wb = self._chk_bytes(workspace, self.inv_workspace_bytes(n), "workspace")
+        check(self._lib.fpgpu_div_dev(self._h, self._chk_t(a, n, "a"), self._chk_t(b, n, "b"), self._chk_t(out, n, "out"),
+                                      fp, n, wp, wb, self._stream()))
         return out
 
     def inv_static_dev(self, x, out, flags):

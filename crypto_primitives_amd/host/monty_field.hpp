@@ -268,6 +268,12 @@ struct DeviceOps {
         fpgpu_check(fpgpu_vec_batch_inv(ctx, x.raw(), out.raw(), none.data(), nullptr));
         return none;
     }
+    // a / b; flags[i] = 1 where checked_div returns None
+    std::vector<uint8_t> div(const DeviceVec& a, const DeviceVec& b, DeviceVec& out) const {
+        std::vector<uint8_t> none(a.size(), 0);
+        fpgpu_check(fpgpu_vec_div(ctx, a.raw(), b.raw(), out.raw(), none.data(), nullptr));
+        return none;
+    }
     void matvec(const DeviceVec& A, size_t rows, size_t cols, const DeviceVec& x, DeviceVec& y) const {
         fpgpu_check(fpgpu_vec_matvec(ctx, A.raw(), rows, cols, x.raw(), y.raw()));
     }
@@ -451,10 +457,20 @@ class MontyField {
     }
     // a[i] / b[i]; panics ("Division by zero") if any divisor has no inverse, like FieldConfig::div.
     std::vector<Element> div_batch(const std::vector<Element>& a, const std::vector<Element>& b) const {
-        auto inv = inv_batch(b);
-        std::vector<Element> ib(b.size());
-        for (size_t i = 0; i < b.size(); i++) { if (!inv[i]) throw std::domain_error("Division by zero"); ib[i] = *inv[i]; }
-        return mul_batch(a, ib);
+        auto q = checked_div_batch(a, b);
+        std::vector<Element> out(a.size());
+        for (size_t i = 0; i < a.size(); i++) { if (!q[i]) throw std::domain_error("Division by zero"); out[i] = *q[i]; }
+        return out;
+    }
+    // checked_div (src/field.rs:168-170) on slices: one device call (inversion + multiplication)
+    std::vector<std::optional<Element>> checked_div_batch(const std::vector<Element>& a, const std::vector<Element>& b) const {
+        if (a.size() != b.size()) throw std::invalid_argument("length mismatch");
+        std::vector<Element> out(a.size());
+        std::vector<uint8_t> none(a.size(), 0);
+        if (!a.empty()) fpgpu_check(fpgpu_div(ctx_.get(), p(a.data()), p(b.data()), p(out.data()), none.data(), a.size()));
+        std::vector<std::optional<Element>> r(a.size());
+        for (size_t i = 0; i < a.size(); i++) if (!none[i]) r[i] = out[i];
+        return r;
     }
     // y = A x : the sum_refs fold of mul over DenseRowMatrix::as_rows()
     std::vector<Element> matvec(const DenseRowMatrix<Element>& A, const std::vector<Element>& x) const {
@@ -511,6 +527,7 @@ class MontyField {
     void div_by_2_batch(const DeviceVec& a, DeviceVec& out) const { on_device().div_by_2(a, out); }
     void pow_batch(const DeviceVec& a, const Integer& e, DeviceVec& out) const { on_device().pow(a, e.words.data(), (uint32_t)LIMBS, out); }
     std::vector<uint8_t> inv_batch(const DeviceVec& x, DeviceVec& out) const { return on_device().inv(x, out); }
+    std::vector<uint8_t> div_batch(const DeviceVec& a, const DeviceVec& b, DeviceVec& out) const { return on_device().div(a, b, out); }
     Element sum_batch(const DeviceVec& v) const { Element r; fpgpu_check(fpgpu_vec_sum(ctx_.get(), v.raw(), p(&r))); return r; }
     Element product_batch(const DeviceVec& v) const { Element r; fpgpu_check(fpgpu_vec_product(ctx_.get(), v.raw(), p(&r))); return r; }
     // sum_refs of mul over two slices (one row of the mat-vec)

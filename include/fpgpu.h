@@ -139,6 +139,12 @@ int fpgpu_product_dev(const fpgpu_ctx *ctx, const void *v, size_t n, void *out, 
 size_t fpgpu_batch_inv_workspace_bytes(const fpgpu_ctx *ctx, size_t n);
 int fpgpu_batch_inv_dev(const fpgpu_ctx *ctx, const void *x, void *out, uint8_t *zero_flags, size_t n,
                         void *workspace, size_t workspace_bytes, void *stream);
+/* FieldConfig::checked_div / div (src/field.rs:155-170): out[i] = mul(a[i], inv(b[i])); where b[i] has no
+ * inverse the reference returns None (div panics "Division by zero"): zero_flags[i] = 1 and out[i] = 0.
+ * One batch inversion and one multiplication on `stream`; out must alias neither a nor b; the workspace is
+ * the batch inversion's (fpgpu_batch_inv_workspace_bytes). */
+int fpgpu_div_dev(const fpgpu_ctx *ctx, const void *a, const void *b, void *out, uint8_t *zero_flags, size_t n,
+                  void *workspace, size_t workspace_bytes, void *stream);
 
 /* Batch inversion that allocates nothing and takes no workspace.  NO COUNTERPART IN THE
  * REFERENCE: it exists for callers that cannot allocate device memory or carry a workspace --
@@ -215,6 +221,7 @@ int fpgpu_sum(const fpgpu_ctx *ctx, const uint64_t *v, size_t n, uint64_t *out);
 int fpgpu_product(const fpgpu_ctx *ctx, const uint64_t *v, size_t n, uint64_t *out);
 int fpgpu_dot(const fpgpu_ctx *ctx, const uint64_t *a, const uint64_t *b, size_t n, uint64_t *out);
 int fpgpu_batch_inv(const fpgpu_ctx *ctx, const uint64_t *x, uint64_t *out, uint8_t *zero_flags, size_t n);
+int fpgpu_div(const fpgpu_ctx *ctx, const uint64_t *a, const uint64_t *b, uint64_t *out, uint8_t *zero_flags, size_t n);
 int fpgpu_matvec(const fpgpu_ctx *ctx, const uint64_t *A, size_t rows, size_t cols, const uint64_t *x,
                  uint64_t *y);
 int fpgpu_spmv(const fpgpu_ctx *ctx, const uint64_t *vals, const uint32_t *col_idx, size_t rows, size_t cols,
@@ -293,6 +300,9 @@ int fpgpu_vec_pow(const fpgpu_ctx *ctx, const fpgpu_vec *a, const uint64_t *expo
  * bytes, HOST) and none_count may be NULL; asking for either makes the call synchronous. */
 int fpgpu_vec_batch_inv(const fpgpu_ctx *ctx, const fpgpu_vec *x, fpgpu_vec *out, uint8_t *none_flags_host,
                         size_t *none_count);
+/* a / b elementwise (checked_div): flags and count as fpgpu_vec_batch_inv; out must alias neither operand */
+int fpgpu_vec_div(const fpgpu_ctx *ctx, const fpgpu_vec *a, const fpgpu_vec *b, fpgpu_vec *out, uint8_t *none_flags_host,
+                  size_t *none_count);
 /* one element to HOST memory (synchronous); per-device partials are folded on the first device */
 int fpgpu_vec_sum(const fpgpu_ctx *ctx, const fpgpu_vec *v, uint64_t *out_host);
 int fpgpu_vec_product(const fpgpu_ctx *ctx, const fpgpu_vec *v, uint64_t *out_host);

@@ -163,8 +163,18 @@ pub trait BatchFieldConfig: GpuMarshal {
     }
     /// `div` (src/field.rs:155-157): panics with "Division by zero" if any divisor has no inverse.
     fn div_batch(&self, a: &[Self::Element], b: &[Self::Element]) -> Result<Vec<Self::Element>, GpuError> {
-        let inv: Vec<Self::Element> = self.inv_batch(b)?.into_iter().map(|o| o.expect("Division by zero")).collect();
-        self.mul_batch(a, &inv)
+        Ok(self.checked_div_batch(a, b)?.into_iter().map(|o| o.expect("Division by zero")).collect())
+    }
+    /// `checked_div` (src/field.rs:168-170): `None` exactly where the divisor has no inverse.  One device call.
+    fn checked_div_batch(&self, a: &[Self::Element], b: &[Self::Element]) -> Result<Vec<Option<Self::Element>>, GpuError> {
+        assert_eq!(a.len(), b.len(), "operand length mismatch");
+        let ctx = self.gpu_ctx()?;
+        let (aw, bw) = (self.gather(a), self.gather(b));
+        let mut ow = vec![0u64; aw.len()];
+        let mut none = vec![0u8; a.len()];
+        // Safety: all four buffers hold a.len() elements / flags.
+        check(unsafe { sys::fpgpu_div(ctx.ptr(), aw.as_ptr(), bw.as_ptr(), ow.as_mut_ptr(), none.as_mut_ptr(), a.len()) })?;
+        Ok(self.scatter(&ow).into_iter().zip(none).map(|(v, f)| (f == 0).then_some(v)).collect())
     }
     /// `pow` (src/field.rs:160) with one exponent for the whole batch.
     fn pow_batch(&self, x: &[Self::Element], e: &Self::Integer) -> Result<Vec<Self::Element>, GpuError> {
@@ -395,6 +405,12 @@ pub trait DeviceBatchFieldConfig: GpuMarshal {
     fn inv_dev(&self, ctx: &GpuCtx, x: &DeviceVec, out: &mut DeviceVec) -> Result<Vec<bool>, GpuError> {
         let mut none = vec![0u8; x.len()];
         check(unsafe { sys::fpgpu_vec_batch_inv(ctx.ptr(), x.ptr(), out.ptr_mut(), none.as_mut_ptr(), core::ptr::null_mut()) })?;
+        Ok(none.into_iter().map(|f| f != 0).collect())
+    }
+    /// `checked_div` on device vectors: flags as `inv_dev`.
+    fn div_dev(&self, ctx: &GpuCtx, a: &DeviceVec, b: &DeviceVec, out: &mut DeviceVec) -> Result<Vec<bool>, GpuError> {
+        let mut none = vec![0u8; a.len()];
+        check(unsafe { sys::fpgpu_vec_div(ctx.ptr(), a.ptr(), b.ptr(), out.ptr_mut(), none.as_mut_ptr(), core::ptr::null_mut()) })?;
         Ok(none.into_iter().map(|f| f != 0).collect())
     }
     fn sum_dev(&self, ctx: &GpuCtx, v: &DeviceVec) -> Result<Self::Element, GpuError> {

@@ -81,6 +81,8 @@ extern "C" {
     pub fn fpgpu_batch_inv_workspace_bytes(ctx: *const fpgpu_ctx, n: usize) -> usize;
     pub fn fpgpu_batch_inv_dev(ctx: *const fpgpu_ctx, x: *const c_void, out: *mut c_void, zero_flags: *mut u8, n: usize,
                                workspace: *mut c_void, workspace_bytes: usize, stream: *mut c_void) -> c_int;
+    pub fn fpgpu_div_dev(ctx: *const fpgpu_ctx, a: *const c_void, b: *const c_void, out: *mut c_void, zero_flags: *mut u8, n: usize,
+                         workspace: *mut c_void, workspace_bytes: usize, stream: *mut c_void) -> c_int;
     /// No counterpart in the reference: batch inversion for callers that cannot allocate (HIP graph
     /// capture, serving loops); the workspace is a static device array of `FPGPU_STATIC_SCRATCH_BYTES`.
     pub fn fpgpu_static_scratch_bytes() -> usize;
@@ -117,6 +119,7 @@ extern "C" {
     pub fn fpgpu_product(ctx: *const fpgpu_ctx, v: *const u64, n: usize, out: *mut u64) -> c_int;
     pub fn fpgpu_dot(ctx: *const fpgpu_ctx, a: *const u64, b: *const u64, n: usize, out: *mut u64) -> c_int;
     pub fn fpgpu_batch_inv(ctx: *const fpgpu_ctx, x: *const u64, out: *mut u64, zero_flags: *mut u8, n: usize) -> c_int;
+    pub fn fpgpu_div(ctx: *const fpgpu_ctx, a: *const u64, b: *const u64, out: *mut u64, zero_flags: *mut u8, n: usize) -> c_int;
     pub fn fpgpu_matvec(ctx: *const fpgpu_ctx, a: *const u64, rows: usize, cols: usize, x: *const u64, y: *mut u64) -> c_int;
     pub fn fpgpu_spmv(ctx: *const fpgpu_ctx, vals: *const u64, col_idx: *const u32, rows: usize, cols: usize,
                       density: usize, x: *const u64, y: *mut u64) -> c_int;
@@ -153,6 +156,8 @@ extern "C" {
                          out: *mut fpgpu_vec) -> c_int;
     pub fn fpgpu_vec_batch_inv(ctx: *const fpgpu_ctx, x: *const fpgpu_vec, out: *mut fpgpu_vec, none_flags_host: *mut u8,
                                none_count: *mut usize) -> c_int;
+    pub fn fpgpu_vec_div(ctx: *const fpgpu_ctx, a: *const fpgpu_vec, b: *const fpgpu_vec, out: *mut fpgpu_vec,
+                         none_flags_host: *mut u8, none_count: *mut usize) -> c_int;
     pub fn fpgpu_vec_sum(ctx: *const fpgpu_ctx, v: *const fpgpu_vec, out_host: *mut u64) -> c_int;
     pub fn fpgpu_vec_product(ctx: *const fpgpu_ctx, v: *const fpgpu_vec, out_host: *mut u64) -> c_int;
     pub fn fpgpu_vec_dot(ctx: *const fpgpu_ctx, a: *const fpgpu_vec, b: *const fpgpu_vec, out_host: *mut u64) -> c_int;

@@ -279,6 +279,12 @@ static void test_gpu_device_vectors() {
         f.add_batch(t, da, u);           // u = a b + a
         f.square_batch(u, t);            // t = u^2
         auto none = f.inv_batch(t, v);   // v = 1 / t   (None where t = 0)
+        {   // checked_div on handles == inversion then multiplication
+            DeviceVec q = f.alloc_device(n, where), q2 = f.alloc_device(n, where);
+            auto none_q = f.div_batch(da, t, q);   // q = a / t
+            f.mul_batch(da, v, q2);               // q2 = a * (1 / t)
+            CHECK(f.from_device(q) == f.from_device(q2) && none_q == none);
+        }
         f.sub_batch(v, db, u);           // u = v - b
         auto got = f.from_device(u);
         size_t bad = 0;

@@ -235,6 +235,49 @@ def test_div_by_zero_raises(cpa):
     assert np.array_equal(f.mul(q, den), a)
 
 
+@pytest.mark.parametrize("name,n", [("bn254_fr", 70001), ("bls12_381_fq", 4099), ("goldilocks", 100003), ("odd_composite_128", 9000)])
+def test_checked_div_three_layers_vs_oracle(cpa, name, n):
+    """FieldConfig::checked_div = mul(a, inv(b)?) (src/field.rs:168-170) as one call: host buffers, device
+    pointers, handles (unset list and a three-entry list) -- quotient and None flags equal the oracle's
+    per-element inv followed by mul; zero divisors at the ends and, for the composite modulus, divisors
+    without an inverse."""
+    import torch
+    g = load_golden(name)
+    p, n64 = h2i(g["modulus"]), g["n64"]
+    f, o = field_of(cpa, g), oracle_of(g)
+    a = ints_to_array(synth_elements(p, n64, n, 71), n64)
+    bs = synth_elements(p, n64, n, 72)
+    for i in (0, 1, n // 2, n - 1):
+        bs[i] = 0
+    if name == "odd_composite_128":
+        bs[17] = 3
+    b = ints_to_array(bs, n64)
+    inv, want_flags = o.batch_inv(b)
+    want = o.mul(a, inv)
+    got, flags = f.checked_div(a, b)
+    assert np.array_equal(flags, want_flags) and np.array_equal(got, want)
+    assert int(flags.sum()) >= 4 and not got[flags == 1].any()
+    # device pointers
+    ta, tb = (torch.from_numpy(x.view(np.int64)).cuda() for x in (a, b))
+    tout, tflags = f.alloc(n), torch.empty(n, dtype=torch.uint8, device="cuda")
+    ws = torch.empty(f.inv_workspace_bytes(n), dtype=torch.uint8, device="cuda")
+    f.div_dev(ta, tb, tout, tflags, ws)
+    assert np.array_equal(tout.cpu().numpy().view(np.uint64), want) and np.array_equal(tflags.cpu().numpy(), want_flags)
+    # handles
+    V = cpa.DeviceVector
+    for ids in (None, [0, 0, 0]):
+        cpa.set_devices(ids or [])
+        try:
+            where = cpa.PLACE_CURRENT if ids is None else cpa.PLACE_SHARDED
+            va, vb, vo = V.from_host(f, a, where), V.from_host(f, b, where), V.alloc(f, n, where)
+            vflags = f.div_vec(va, vb, vo)
+            assert np.array_equal(vo.download(), want) and np.array_equal(vflags, want_flags)
+            with pytest.raises(cpa.FpgpuError):
+                f.div_vec(va, vb, va)                  # out must not alias an operand
+        finally:
+            cpa.set_devices([])
+
+
 def test_even_modulus_rejected(cpa):
     with pytest.raises(cpa.InvalidModulus):
         cpa.MontyField(42, 4)
