@@ -79,3 +79,51 @@ def test_random_programs_on_random_odd_moduli(case):
     assert np.array_equal(f.mul(regs_h[0], regs_h[1]), o.mul(regs_h[0], regs_h[1]))
     assert np.array_equal(f.sum_vec(regs_d[2]), o.sum(regs_h[2]))
     assert np.array_equal(f.dot_vec(regs_d[0], regs_d[3]), o.sum(o.mul(regs_h[0], regs_h[3])))
+
+
+@st.composite
+def matrix_cases(draw):
+    n64 = draw(st.integers(1, 8))
+    bits = draw(st.integers(max(2, 64 * (n64 - 1) + 2), 64 * n64))
+    p = draw(st.integers(1 << (bits - 1), (1 << bits) - 1)) | 1
+    rows = draw(st.integers(1, 150))
+    cols = draw(st.integers(1, 300))
+    inner = draw(st.integers(1, 70))
+    density = draw(st.integers(0, 9))
+    layout = draw(st.sampled_from([None, [0], [0, 0, 0]]))
+    seed = draw(st.integers(0, 2**32 - 1))
+    return n64, p, rows, cols, inner, density, layout, seed
+
+
+@settings(max_examples=_SOAK or 50, deadline=None, derandomize=not _SOAK, suppress_health_check=list(HealthCheck))
+@given(matrix_cases())
+def test_random_matrix_products_on_random_odd_moduli(case):
+    """Mat-vec (host call = matrix cores where the shape allows, VALU kernel otherwise; and on handles, row-sharded
+    with the output gathered), mat-mul (single-limb matrix-core / VALU and multi-limb kernels) and sparse mat-vec
+    on random shapes and random odd moduli of every width, extreme elements mixed in."""
+    import crypto_primitives_amd as cpa
+    from oracle.fp_oracle import Oracle
+    n64, p, rows, cols, inner, density, layout, seed = case
+    f, o = cpa.MontyField(p, n64), Oracle(p, n64)
+    rnd = random.Random(seed)
+    el = lambda k: ints_to_array([rnd.choice((0, 1, p - 1)) if rnd.random() < 0.15 else rnd.randrange(p) for _ in range(k)], n64)
+    A, x = el(rows * cols), el(cols)
+    want = o.matvec(A, rows, cols, x, threads=0)
+    assert np.array_equal(f.matvec(A, rows, cols, x), want), ("matvec", hex(p), rows, cols)
+    V = cpa.DeviceVector
+    cpa.set_devices(layout or [])
+    try:
+        sharded, repl = (cpa.PLACE_CURRENT, cpa.PLACE_CURRENT) if layout is None else (cpa.PLACE_SHARDED, cpa.PLACE_REPLICATED)
+        vA, vx, vy = V.from_host(f, A, sharded, row_len=cols), V.from_host(f, x, repl), V.alloc(f, rows, repl)
+        f.matvec_vec(vA, rows, cols, vx, vy)
+        assert np.array_equal(vy.download(), want), ("matvec handles", hex(p), rows, cols, layout)
+        if density:
+            vals = el(rows * density)
+            idx = np.array([rnd.randrange(cols) for _ in range(rows * density)], dtype=np.uint32)
+            swant = o.spmv(vals, idx, rows, cols, density, x)
+            assert np.array_equal(f.spmv(vals, idx, rows, cols, density, x), swant), ("spmv", hex(p), rows, cols, density)
+    finally:
+        cpa.set_devices([])
+    m, k, n = min(rows, 40), inner, min(cols, 45)
+    Am, Bm = el(m * k), el(k * n)
+    assert np.array_equal(f.matmul(Am, Bm, m, k, n), o.matmul(Am, Bm, m, k, n, threads=0)), ("matmul", hex(p), m, k, n)
