@@ -131,3 +131,40 @@ def test_config4_matmul_8192_goldilocks(cpa):
         assert np.array_equal(_host(C[r * dim:(r + 1) * dim]).reshape(-1), want.reshape(-1))
     del A, B, C, ws
     torch.cuda.empty_cache()
+
+
+def test_more_than_2pow32_elements_in_one_call(cpa):
+    """A 288 GB part holds vectors of more than 2^32 elements: 2^32 + 12345 Goldilocks elements (32 GiB per
+    vector) through the streaming kernels, the generator, the folds and the dot product -- every element index
+    and byte offset beyond 32 bits.  Laws instead of an oracle pass over the bulk, the oracle on samples from
+    both ends of the index range."""
+    import torch
+    f, o = cpa.MontyField(cpa.GOLDILOCKS, 1), _oracle("goldilocks")
+    n = (1 << 32) + 12345
+    free, _ = torch.cuda.mem_get_info()
+    if free < 3 * 8 * n + (4 << 30):
+        pytest.skip("needs 100 GiB of free device memory")
+    a, b, t = f.random_dev(n, 201), f.random_dev(n, 202), f.alloc(n)
+    ws = torch.empty(f.fold_workspace_bytes(), dtype=torch.uint8, device="cuda")
+
+    def total(v, w=None):
+        out = f.alloc(1)
+        (f.sum_dev(v, out, ws) if w is None else f.dot_dev(v, w, out, ws))
+        return _host(out).reshape(1, 1)
+
+    idx = torch.cat([torch.arange(0, 4096, device="cuda"), torch.arange(n - 4096, n, device="cuda"),
+                     torch.arange(0, n, 1048573, device="cuda")])
+    ha, hb = _host(a[idx]), _host(b[idx])
+    f.mul_dev(a, b, t)
+    assert np.array_equal(_host(t[idx]), o.mul(ha, hb))
+    assert np.array_equal(total(a, b), total(t))                         # dot(a, b) == sum(a * b)
+    f.neg_dev(a, t)
+    assert np.array_equal(_host(t[idx]), o.neg(ha))
+    s_a, s_na = total(a), total(t)
+    assert np.array_equal(o.add(s_a, s_na), np.zeros((1, 1), dtype=np.uint64))   # sum(a) + sum(-a) == 0
+    f.sub_dev(a, b, t)
+    f.add_dev(t, b, t)
+    assert torch.equal(t[-(1 << 20):], a[-(1 << 20):]) and torch.equal(t[:1 << 20], a[:1 << 20])   # (a - b) + b == a
+    assert np.array_equal(total(t), s_a)
+    del a, b, t
+    torch.cuda.empty_cache()
