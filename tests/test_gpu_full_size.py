@@ -142,8 +142,8 @@ def test_more_than_2pow32_elements_in_one_call(cpa):
     f, o = cpa.MontyField(cpa.GOLDILOCKS, 1), _oracle("goldilocks")
     n = (1 << 32) + 12345
     free, _ = torch.cuda.mem_get_info()
-    if free < 3 * 8 * n + (4 << 30):
-        pytest.skip("needs 100 GiB of free device memory")
+    if free < 3 * 8 * n + n + (16 << 30):
+        pytest.skip("needs 120 GiB of free device memory")
     a, b, t = f.random_dev(n, 201), f.random_dev(n, 202), f.alloc(n)
     ws = torch.empty(f.fold_workspace_bytes(), dtype=torch.uint8, device="cuda")
 
@@ -166,5 +166,19 @@ def test_more_than_2pow32_elements_in_one_call(cpa):
     f.add_dev(t, b, t)
     assert torch.equal(t[-(1 << 20):], a[-(1 << 20):]) and torch.equal(t[:1 << 20], a[:1 << 20])   # (a - b) + b == a
     assert np.array_equal(total(t), s_a)
-    del a, b, t
+    # batch inversion over the same count: chain indices c + k M beyond 2^32, three levels of totals
+    flags = torch.empty(n, dtype=torch.uint8, device="cuda")
+    iws = torch.empty(f.inv_workspace_bytes(n), dtype=torch.uint8, device="cuda")
+    a[n - 1].zero_()
+    a[1 << 32].zero_()
+    f.inv_dev(a, t, flags, iws)
+    f.mul_dev(a, t, b)                                                   # b = a * inv(a)
+    one = int(torch.from_numpy(f.one_words.view(np.int64))[0])
+    nz = int(flags.sum())
+    assert nz >= 2 and bool(flags[n - 1]) and bool(flags[1 << 32])
+    assert int((b.view(-1) == one).sum()) == n - nz and int((b.view(-1) == 0).sum()) == nz
+    ha = _host(a[idx])
+    winv, wflags = o.batch_inv(ha)
+    assert np.array_equal(_host(t[idx]), winv) and np.array_equal(flags[idx].cpu().numpy(), wflags)
+    del a, b, t, flags, iws
     torch.cuda.empty_cache()
