@@ -240,8 +240,17 @@ hipError_t Launch<N>::spmv(const fpgpu_ctx* ctx, const void* vals, const uint32_
     size_t blocks = (lanes + kBlock - 1) / kBlock;
     if (blocks > (1u << 20)) blocks = 1u << 20;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL((k_spmv<N>), dim3((unsigned)blocks), dim3(kBlock), 0, s, (const uint32_t*)vals, colidx,
-                       (const uint32_t*)x, (uint32_t*)y, rows, cols, density, log2g, make_params<N>(ctx));
+    // cells a lane loads together: what it owns, at most 4
+    const uint32_t per_lane = (density + (1u << log2g) - 1) >> log2g;
+    long u = per_lane >= 4 ? 4 : (per_lane >= 2 ? 2 : 1);
+    if (const long v = tuning().spmv_unroll; v == 1 || v == 2 || v == 4) u = v;  // tuning / tests
+    auto launch = [&](auto kernel) {
+        hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(kBlock), 0, s, (const uint32_t*)vals, colidx,
+                           (const uint32_t*)x, (uint32_t*)y, rows, cols, density, log2g, make_params<N>(ctx));
+    };
+    if (u == 4) launch(k_spmv<N, 4>);
+    else if (u == 2) launch(k_spmv<N, 2>);
+    else launch(k_spmv<N, 1>);
     return hipSuccess;
 }
 

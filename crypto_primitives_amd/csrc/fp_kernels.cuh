@@ -566,7 +566,11 @@ __global__ __launch_bounds__(kBlock) void k_matvec(const uint32_t* __restrict__ 
 // add as the dense product.  G = 2^log2g lanes share a row (chosen by the launcher, at most 64): values are read coalesced, x is gathered, products are accumulated
 // lazily per lane (as k_matvec) and the G partial residues are summed with a butterfly.
 // A column index >= cols contributes nothing (the host entry point rejects such input).
-template <int N>
+// A lane takes its cells U at a time: the U column indices and values are loaded first, then the U elements of
+// x are gathered together, then the products are formed -- one dependent memory latency (index -> x) per U
+// cells instead of one per cell, and no branch around a load (a cell that does not exist, or whose column is
+// out of range, reads a valid address and multiplies by zero).
+template <int N, int U>
 __global__ __launch_bounds__(kBlock) void k_spmv(const uint32_t* __restrict__ vals, const uint32_t* __restrict__ colidx,
                                                  const uint32_t* __restrict__ x, uint32_t* __restrict__ y, size_t rows,
                                                  size_t cols, uint32_t density, uint32_t log2g, const FpParams<N> P) {
@@ -579,15 +583,31 @@ __global__ __launch_bounds__(kBlock) void k_spmv(const uint32_t* __restrict__ va
         uint32_t S[2 * N];
 #pragma unroll
         for (int l = 0; l < 2 * N; l++) S[l] = 0;
-        if (row < rows) {
-            for (uint32_t j = sub; j < density; j += G) {
-                const size_t cell = row * density + j;
-                const uint32_t c = colidx[cell];
-                if (c < cols) {
-                    uint32_t a[1][N], b[1][N], prod[2 * N];
-                    load_elem<N>(a[0], vals, cell);
-                    load_elem<N>(b[0], x, c);
-                    mul_wide_sum<N, 1>(prod, a, b);
+        if (row < rows && cols > 0) {
+            for (uint32_t j0 = sub; j0 < density; j0 += U * G) {
+                uint32_t c[U], a[U][1][N], b[U][1][N];
+                bool ok[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const uint32_t j = j0 + (uint32_t)u * G;
+                    ok[u] = j < density;
+                    const size_t cell = row * density + (ok[u] ? j : j0);   // j0 < density: a cell that exists
+                    c[u] = colidx[cell];
+                    load_elem<N>(a[u][0], vals, cell);
+                }
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    ok[u] = ok[u] && c[u] < cols;
+                    load_elem<N>(b[u][0], x, ok[u] ? c[u] : 0u);
+                }
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    if (!ok[u]) {
+#pragma unroll
+                        for (int l = 0; l < N; l++) a[u][0][l] = 0;
+                    }
+                    uint32_t prod[2 * N];
+                    mul_wide_sum<N, 1>(prod, a[u], b[u]);
                     wide_acc_add<N>(S, prod, P);
                 }
             }

@@ -115,6 +115,7 @@ struct Tuning {
     long matmul_mfma = -1;    // FPGPU_MATMUL_MFMA: 0 forces the VALU single-limb mat-mul
     long matmul_generic = 0;  // FPGPU_MATMUL_GENERIC: 1 forces the multi-limb mat-mul kernel
     long spmv_log2g = -1;     // FPGPU_SPMV_LOG2G: log2 of the lanes sharing a sparse row
+    long spmv_unroll = 0;     // FPGPU_SPMV_UNROLL: cells a lane of the sparse mat-vec loads together (1, 2 or 4)
     long pow_window = -1;     // FPGPU_POW_WINDOW: 0 forces the binary pow ladder, 1 the sliding-window one
     long copy_threads = 0;    // FPGPU_COPY_THREADS: host threads that fill / drain the pinned staging buffers (1 = plain hipMemcpy)
     long allgather_copy = 0;  // FPGPU_ALLGATHER_COPY: 1 = peer copies instead of RCCL for the all-gather

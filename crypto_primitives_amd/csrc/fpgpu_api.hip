@@ -109,7 +109,7 @@ static const TuningEntry kTuningEntries[] = {
     {"FPGPU_MATVEC_T", &Tuning::matvec_t},         {"FPGPU_MATMUL_MFMA", &Tuning::matmul_mfma},
     {"FPGPU_MATMUL_GENERIC", &Tuning::matmul_generic}, {"FPGPU_SPMV_LOG2G", &Tuning::spmv_log2g},
     {"FPGPU_ALLGATHER_COPY", &Tuning::allgather_copy}, {"FPGPU_COPY_THREADS", &Tuning::copy_threads},
-    {"FPGPU_POW_WINDOW", &Tuning::pow_window},
+    {"FPGPU_POW_WINDOW", &Tuning::pow_window},         {"FPGPU_SPMV_UNROLL", &Tuning::spmv_unroll},
 };
 static Tuning g_tuning_defaults;
 static Tuning g_tuning;

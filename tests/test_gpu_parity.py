@@ -313,10 +313,16 @@ def test_matvec_multi_term_passes(cpa, T, tuning):
 
 @pytest.mark.parametrize("shape", [(1, 1, 1), (5, 9, 3), (300, 1000, 7), (33, 50, 64), (17, 400, 100), (9, 70, 200),
                                    (4, 6, 0), (70001, 4096, 4)])
-def test_spmv_vs_oracle(cpa, shape):
+@pytest.mark.parametrize("unroll,log2g", [(0, -1), (1, 2), (2, 0), (4, 1), (4, 3), (2, 6)])
+def test_spmv_vs_oracle(cpa, tuning, shape, unroll, log2g):
     """SparseMatrix (src/matrix.rs:46-61: `density` (column, value) cells per row) times vector ==
-    the oracle's fold of mul then add; repeated columns inside a row are legal and summed."""
+    the oracle's fold of mul then add; repeated columns inside a row are legal and summed.  Default
+    geometry and forced ones: 1, 2 or 4 cells per lane loaded together, 1 to 64 lanes per row (rows shorter
+    than a lane's batch, batches that run past the end of the row)."""
     rows, cols, density = shape
+    if unroll:
+        tuning("FPGPU_SPMV_UNROLL", unroll)
+        tuning("FPGPU_SPMV_LOG2G", log2g)
     rng = np.random.default_rng(rows + cols + density)
     for name in ("bn254_fr", "goldilocks", "bls12_381_fq"):
         g = load_golden(name)
