@@ -311,19 +311,33 @@ struct DevBuf {
 
 }  // namespace
 
+// The lanes need pinned host memory, streams and threads; where the process may not have them (a locked-
+// memory limit, no more streams) the transfers still work, through the runtime's own staging: the failure
+// is remembered and every later transfer takes the plain path.
+static bool g_lanes_unavailable = false;
+static DeviceLanes* lanes_or_null(int lanes, bool device_slots) {
+    if (g_lanes_unavailable) return nullptr;
+    DeviceLanes* d = nullptr;
+    if (acquire(lanes, &d) == FPGPU_OK && (!device_slots || ensure_device_slots(d, lanes) == FPGPU_OK)) return d;
+    (void)hipGetLastError();
+    g_lanes_unavailable = true;
+    return nullptr;
+}
+static int plain_copy(void* dst, const void* src, size_t bytes, hipMemcpyKind kind, hipStream_t stream) {
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, kind, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    return FPGPU_OK;
+}
+
 // dev <- host (pageable), ordered after everything queued on `stream` of the current device; returns when
 // the data is in device memory (so later work on any stream sees it and `host` is the caller's again).
 int upload_staged(void* dev, const void* host, size_t bytes, hipStream_t stream) {
     if (bytes == 0) return FPGPU_OK;
     const int lanes = lanes_wanted();
-    if (bytes < kMinStaged || lanes == 1) {
-        HIP_TRY(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, stream));
-        HIP_TRY(hipStreamSynchronize(stream));
-        return FPGPU_OK;
-    }
+    if (bytes < kMinStaged || lanes == 1) return plain_copy(dev, host, bytes, hipMemcpyHostToDevice, stream);
     std::lock_guard<std::mutex> lock(g_stage.mu);
-    DeviceLanes* d = nullptr;
-    CHECK(acquire(lanes, &d));
+    DeviceLanes* d = lanes_or_null(lanes, false);
+    if (!d) return plain_copy(dev, host, bytes, hipMemcpyHostToDevice, stream);
     HIP_TRY(hipEventRecord(d->order, stream));
     HIP_TRY(hipStreamWaitEvent(d->up, d->order, 0));
     return run_lanes(d, lanes, [&](int t) { return lane_upload(d, t, lanes, (char*)dev, (const char*)host, bytes); });
@@ -333,14 +347,10 @@ int upload_staged(void* dev, const void* host, size_t bytes, hipStream_t stream)
 int download_staged(void* host, const void* dev, size_t bytes, hipStream_t stream) {
     if (bytes == 0) return FPGPU_OK;
     const int lanes = lanes_wanted();
-    if (bytes < kMinStaged || lanes == 1) {
-        HIP_TRY(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipStreamSynchronize(stream));
-        return FPGPU_OK;
-    }
+    if (bytes < kMinStaged || lanes == 1) return plain_copy(host, dev, bytes, hipMemcpyDeviceToHost, stream);
     std::lock_guard<std::mutex> lock(g_stage.mu);
-    DeviceLanes* d = nullptr;
-    CHECK(acquire(lanes, &d));
+    DeviceLanes* d = lanes_or_null(lanes, false);
+    if (!d) return plain_copy(host, dev, bytes, hipMemcpyDeviceToHost, stream);
     HIP_TRY(hipEventRecord(d->order, stream));
     return run_lanes(d, lanes, [&](int t) { return lane_download(d, t, lanes, (char*)host, (const char*)dev, bytes); });
 }
@@ -348,26 +358,27 @@ int download_staged(void* host, const void* dev, size_t bytes, hipStream_t strea
 // out[i] = op(a[i], b[i]) for host arrays: `call(da, db, dout, count, stream)` queues the operation on
 // `count` elements that lie in device memory (db == nullptr when b is).  Small batches, or one copy
 // thread: whole operands on the device through plain copies; otherwise the chunk pipeline above.
+static int whole_operands_elementwise(const void* a, const void* b, void* out, size_t n, size_t bytes, const ChunkCall& call) {
+    DevBuf da, db, dout;
+    CHECK(da.alloc(bytes));
+    if (b) CHECK(db.alloc(bytes));
+    CHECK(dout.alloc(bytes));
+    HIP_TRY(hipMemcpyAsync(da.p, a, bytes, hipMemcpyHostToDevice, nullptr));
+    if (b) HIP_TRY(hipMemcpyAsync(db.p, b, bytes, hipMemcpyHostToDevice, nullptr));
+    CHECK(call(da.p, db.p, dout.p, n, nullptr));
+    HIP_TRY(hipMemcpyAsync(out, dout.p, bytes, hipMemcpyDeviceToHost, nullptr));
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    return FPGPU_OK;
+}
+
 int host_stream_elementwise(const void* a, const void* b, void* out, size_t n, size_t esz, const ChunkCall& call) {
     if (n == 0) return FPGPU_OK;
     const int lanes = lanes_wanted();
     const size_t bytes = n * esz;
-    if (bytes < kMinStaged || lanes == 1) {
-        DevBuf da, db, dout;
-        CHECK(da.alloc(bytes));
-        if (b) CHECK(db.alloc(bytes));
-        CHECK(dout.alloc(bytes));
-        HIP_TRY(hipMemcpyAsync(da.p, a, bytes, hipMemcpyHostToDevice, nullptr));
-        if (b) HIP_TRY(hipMemcpyAsync(db.p, b, bytes, hipMemcpyHostToDevice, nullptr));
-        CHECK(call(da.p, db.p, dout.p, n, nullptr));
-        HIP_TRY(hipMemcpyAsync(out, dout.p, bytes, hipMemcpyDeviceToHost, nullptr));
-        HIP_TRY(hipStreamSynchronize(nullptr));
-        return FPGPU_OK;
-    }
+    if (bytes < kMinStaged || lanes == 1) return whole_operands_elementwise(a, b, out, n, bytes, call);
     std::lock_guard<std::mutex> lock(g_stage.mu);
-    DeviceLanes* d = nullptr;
-    CHECK(acquire(lanes, &d));
-    CHECK(ensure_device_slots(d, lanes));
+    DeviceLanes* d = lanes_or_null(lanes, true);
+    if (!d) return whole_operands_elementwise(a, b, out, n, bytes, call);
     const size_t per = std::max<size_t>((kLaneChunk / esz) & ~(size_t)31, 32);   // whole elements, 256-byte multiples
     return run_lanes(d, lanes, [&](int t) {
         return lane_elementwise(d, t, lanes, (const char*)a, (const char*)b, (char*)out, n, esz, per, call);
