@@ -600,11 +600,36 @@ int fpgpu_dot(const fpgpu_ctx* ctx, const uint64_t* a, const uint64_t* b, size_t
     return FPGPU_OK;
 }
 
+// Large host batches of inversions / divisions: independent ranges through the chunk pipeline (each range its
+// own Montgomery trick; an inverse does not depend on how the batch is cut), copies in both directions
+// overlapping the kernels.  FPGPU_ERR_UNSUPPORTED = take the whole-operand path.
+static int inv_or_div_streamed(const fpgpu_ctx* ctx, const uint64_t* a, const uint64_t* b, uint64_t* out, uint8_t* zero_flags,
+                               size_t n) {
+    if (!host_stream_usable(n * (size_t)ctx->n64 * 8)) return FPGPU_ERR_UNSUPPORTED;
+    StreamJob job;
+    job.a = a ? (const void*)a : (const void*)b;   // division: a | b; inversion: x alone
+    job.b = a ? b : nullptr;
+    job.out = out;
+    job.flags = zero_flags;
+    job.want_flags = true;
+    job.n = n;
+    job.esz = (size_t)ctx->n64 * 8;
+    job.lane_compute = true;
+    job.workspace_for = [ctx](size_t count) { return fpgpu_batch_inv_workspace_bytes(ctx, count); };
+    const bool div = a != nullptr;
+    job.call = [ctx, div](void* da, void* db, void* dout, uint8_t* dflags, void* ws, size_t wsb, size_t cnt, hipStream_t s) {
+        return div ? fpgpu_div_dev(ctx, da, db, dout, dflags, cnt, ws, wsb, s)
+                   : fpgpu_batch_inv_dev(ctx, da, dout, dflags, cnt, ws, wsb, s);
+    };
+    return host_stream_map(job);
+}
+
 int fpgpu_batch_inv(const fpgpu_ctx* ctx, const uint64_t* x, uint64_t* out, uint8_t* zero_flags, size_t n) {
     CHECK(check_common(ctx, n));
     if (n == 0) return FPGPU_OK;
     if (!x || !out) return fail(FPGPU_ERR_SHAPE, "null host pointer");
     CHECK(require_device());
+    if (const int rc = inv_or_div_streamed(ctx, nullptr, x, out, zero_flags, n); rc != FPGPU_ERR_UNSUPPORTED) return rc;
     size_t bytes = n * ctx->n64 * 8;
     size_t wsb = fpgpu_batch_inv_workspace_bytes(ctx, n);
     DevBuf dx, dout, dflags, ws;
@@ -625,6 +650,7 @@ int fpgpu_div(const fpgpu_ctx* ctx, const uint64_t* a, const uint64_t* b, uint64
     if (n == 0) return FPGPU_OK;
     if (!a || !b || !out) return fail(FPGPU_ERR_SHAPE, "null host pointer");
     CHECK(require_device());
+    if (const int rc = inv_or_div_streamed(ctx, a, b, out, zero_flags, n); rc != FPGPU_ERR_UNSUPPORTED) return rc;
     size_t bytes = n * ctx->n64 * 8;
     size_t wsb = fpgpu_batch_inv_workspace_bytes(ctx, n);
     DevBuf da, db, dout, dflags, ws;

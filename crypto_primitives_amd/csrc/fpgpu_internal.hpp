@@ -24,6 +24,23 @@ int download_staged(void* host, const void* dev, size_t bytes, hipStream_t strea
 // call above 4 MiB; synchronous.
 using ChunkCall = std::function<int(void* da, void* db, void* dout, size_t count, hipStream_t stream)>;
 int host_stream_elementwise(const void* a, const void* b, void* out, size_t n, size_t esz, const ChunkCall& call);
+// The same pipeline for any map over independent element ranges: operands a (and b), result out, optionally
+// one flag byte per element to the host, optionally a device workspace per chunk (workspace_for(count) bytes).
+// `call` queues the chunk's kernels on the stream it is given.  lane_compute: the chunk's kernels are
+// latency-bound (a batch inversion), so they run on the chunk's own stream and overlap with other chunks'.
+struct StreamJob {
+    const void* a = nullptr;
+    const void* b = nullptr;
+    void* out = nullptr;
+    uint8_t* flags = nullptr;      // host, may be NULL even when the kernels need a device flag array
+    bool want_flags = false;       // the kernels write one flag byte per element
+    size_t n = 0, esz = 0;
+    bool lane_compute = false;
+    std::function<size_t(size_t count)> workspace_for;
+    std::function<int(void* da, void* db, void* dout, uint8_t* dflags, void* ws, size_t ws_bytes, size_t count, hipStream_t s)> call;
+};
+bool host_stream_usable(size_t bytes);
+int host_stream_map(const StreamJob& job);   // FPGPU_ERR_UNSUPPORTED: not available, nothing was done
 
 }  // namespace fpgpu
 

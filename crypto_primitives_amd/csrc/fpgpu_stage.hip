@@ -259,11 +259,36 @@ int lane_download(DeviceLanes* d, int t, int T, char* host, const char* dev, siz
     return FPGPU_OK;
 }
 
-// chunk j of lane t: up (a | b in one DMA) on the upload stream, kernel on the compute stream, down on the lane's own;
-// two rounds later the lane copies the result out of the pinned buffer and reuses the slot.
-int lane_elementwise(DeviceLanes* d, int t, int T, const char* a, const char* b, char* out, size_t n, size_t esz,
-                     size_t per, const ChunkCall& call) {
+// Slot layout of the chunk pipeline (device and pinned alike), every region 256-byte aligned:
+//   a | b (if any) | out | flags (if any) | workspace (device only)
+struct SlotPlan {
+    size_t per;                      // elements per chunk
+    size_t b_off, out_off, flags_off, ws_off, ws_bytes;
+};
+inline size_t up256(size_t v) { return (v + 255) & ~(size_t)255; }
+SlotPlan plan_slot(const StreamJob& job, size_t per) {
+    SlotPlan p{};
+    p.per = per;
+    size_t off = up256(per * job.esz);
+    p.b_off = off;
+    if (job.b) off += up256(per * job.esz);
+    p.out_off = off;
+    off += up256(per * job.esz);
+    p.flags_off = off;
+    if (job.want_flags) off += up256(per);
+    p.ws_off = off;
+    p.ws_bytes = job.workspace_for ? job.workspace_for(per) : 0;
+    return p;
+}
+inline size_t slot_bytes(const SlotPlan& p) { return p.ws_off + up256(p.ws_bytes); }
+
+// chunk j of lane t: up (a | b in one DMA) on the upload stream; the kernels on the shared compute stream, or
+// on the lane's own when a chunk's kernels are latency-bound (several chunks then run side by side); down
+// (out | flags in one DMA) on the lane's own; two rounds later the lane copies the result out of the pinned
+// buffer and reuses the slot.
+int lane_map(DeviceLanes* d, int t, int T, const StreamJob& job, const SlotPlan& sp) {
     Lane& L = d->lanes[t];
+    const size_t esz = job.esz, per = sp.per, n = job.n;
     const size_t mine = lane_chunks((n + per - 1) / per, t, T);
     for (size_t j = 0; j < mine + 2; j++) {
         const int s = (int)(j & 1);
@@ -271,23 +296,27 @@ int lane_elementwise(DeviceLanes* d, int t, int T, const char* a, const char* b,
         if (j >= 2) {
             const size_t first = (t + (j - 2) * T) * per, cnt = std::min(per, n - first);
             HIP_TRY(hipEventSynchronize(L.ev[s]));
-            std::memcpy(out + first * esz, pin + 2 * kLaneChunk, cnt * esz);
+            std::memcpy((char*)job.out + first * esz, pin + sp.out_off, cnt * esz);
+            if (job.flags) std::memcpy(job.flags + first, pin + sp.flags_off, cnt);
         }
         if (j < mine) {
             const size_t first = (t + j * T) * per, cnt = std::min(per, n - first), bytes = cnt * esz;
-            const size_t boff = b ? (bytes + 255) & ~(size_t)255 : 0;   // b right behind a: one DMA for both
-            std::memcpy(pin, a + first * esz, bytes);
-            if (b) std::memcpy(pin + boff, b + first * esz, bytes);
+            std::memcpy(pin, (const char*)job.a + first * esz, bytes);
+            if (job.b) std::memcpy(pin + sp.b_off, (const char*)job.b + first * esz, bytes);
+            char* dev = L.dev[s];
+            hipStream_t cs = job.lane_compute ? L.stream : d->compute;
             {
                 std::lock_guard<std::mutex> issue(d->issue);
-                HIP_TRY(hipMemcpyAsync(L.dev[s], pin, boff + bytes, hipMemcpyHostToDevice, d->up));
+                HIP_TRY(hipMemcpyAsync(dev, pin, job.b ? sp.b_off + bytes : bytes, hipMemcpyHostToDevice, d->up));
                 HIP_TRY(hipEventRecord(L.uploaded[s], d->up));
-                HIP_TRY(hipStreamWaitEvent(d->compute, L.uploaded[s], 0));
-                CHECK(call(L.dev[s], b ? L.dev[s] + boff : nullptr, L.dev[s] + 2 * kLaneChunk, cnt, d->compute));
-                HIP_TRY(hipEventRecord(L.computed[s], d->compute));
+                HIP_TRY(hipStreamWaitEvent(cs, L.uploaded[s], 0));
+                CHECK(job.call(dev, job.b ? dev + sp.b_off : nullptr, dev + sp.out_off,
+                               job.want_flags ? (uint8_t*)(dev + sp.flags_off) : nullptr, dev + sp.ws_off, sp.ws_bytes, cnt, cs));
+                if (!job.lane_compute) HIP_TRY(hipEventRecord(L.computed[s], d->compute));
             }
-            HIP_TRY(hipStreamWaitEvent(L.stream, L.computed[s], 0));
-            HIP_TRY(hipMemcpyAsync(pin + 2 * kLaneChunk, L.dev[s] + 2 * kLaneChunk, bytes, hipMemcpyDeviceToHost, L.stream));
+            if (!job.lane_compute) HIP_TRY(hipStreamWaitEvent(L.stream, L.computed[s], 0));
+            const size_t down = job.want_flags ? (sp.flags_off - sp.out_off) + cnt : bytes;   // out | flags in one DMA
+            HIP_TRY(hipMemcpyAsync(pin + sp.out_off, dev + sp.out_off, down, hipMemcpyDeviceToHost, L.stream));
             HIP_TRY(hipEventRecord(L.ev[s], L.stream));
         }
     }
@@ -371,18 +400,43 @@ static int whole_operands_elementwise(const void* a, const void* b, void* out, s
     return FPGPU_OK;
 }
 
-int host_stream_elementwise(const void* a, const void* b, void* out, size_t n, size_t esz, const ChunkCall& call) {
-    if (n == 0) return FPGPU_OK;
+// Whether a host-array call of this size takes the chunk pipeline (else: whole operands on the device).
+bool host_stream_usable(size_t bytes) { return bytes >= kMinStaged && lanes_wanted() > 1 && !g_lanes_unavailable; }
+
+// The chunk pipeline for any per-element map of host arrays (see StreamJob): returns FPGPU_ERR_UNSUPPORTED
+// without touching anything when the lanes cannot be had -- the caller then takes its whole-operand path.
+int host_stream_map(const StreamJob& job) {
+    if (job.n == 0) return FPGPU_OK;
     const int lanes = lanes_wanted();
-    const size_t bytes = n * esz;
-    if (bytes < kMinStaged || lanes == 1) return whole_operands_elementwise(a, b, out, n, bytes, call);
+    if (lanes == 1) return FPGPU_ERR_UNSUPPORTED;
     std::lock_guard<std::mutex> lock(g_stage.mu);
     DeviceLanes* d = lanes_or_null(lanes, true);
-    if (!d) return whole_operands_elementwise(a, b, out, n, bytes, call);
-    const size_t per = std::max<size_t>((kLaneChunk / esz) & ~(size_t)31, 32);   // whole elements, 256-byte multiples
-    return run_lanes(d, lanes, [&](int t) {
-        return lane_elementwise(d, t, lanes, (const char*)a, (const char*)b, (char*)out, n, esz, per, call);
-    });
+    if (!d) return FPGPU_ERR_UNSUPPORTED;
+    // the largest chunk (a multiple of 32 elements) whose slot fits
+    size_t per = (kSlotBytes / (job.esz * (job.b ? 3 : 2) + 1)) & ~(size_t)31;
+    while (per > 32 && slot_bytes(plan_slot(job, per)) > kSlotBytes) per -= std::max<size_t>(32, (per / 16) & ~(size_t)31);
+    if (per < 32 || slot_bytes(plan_slot(job, per)) > kSlotBytes) return FPGPU_ERR_UNSUPPORTED;
+    const SlotPlan sp = plan_slot(job, per);
+    return run_lanes(d, lanes, [&](int t) { return lane_map(d, t, lanes, job, sp); });
+}
+
+int host_stream_elementwise(const void* a, const void* b, void* out, size_t n, size_t esz, const ChunkCall& call) {
+    if (n == 0) return FPGPU_OK;
+    const size_t bytes = n * esz;
+    if (host_stream_usable(bytes)) {
+        StreamJob job;
+        job.a = a;
+        job.b = b;
+        job.out = out;
+        job.n = n;
+        job.esz = esz;
+        job.call = [&](void* da, void* db, void* dout, uint8_t*, void*, size_t, size_t cnt, hipStream_t s) {
+            return call(da, db, dout, cnt, s);
+        };
+        const int rc = host_stream_map(job);
+        if (rc != FPGPU_ERR_UNSUPPORTED) return rc;
+    }
+    return whole_operands_elementwise(a, b, out, n, bytes, call);
 }
 
 }  // namespace fpgpu

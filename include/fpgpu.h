@@ -32,10 +32,12 @@
  * synchronous and run on the current device; their host <-> device copies go
  * through pinned staging buffers of the library, filled and drained by a few
  * host threads (pageable caller memory cannot be pinned in place).  The
- * elementwise ones (fpgpu_mul ... fpgpu_pow) stream their operands through the
- * device in chunks -- copy in, kernel and copy out overlap, `out` may be `a`
- * or `b`, and the arrays may exceed device memory; the others hold whole
- * operands in device memory they allocate and free themselves.  The library
+ * elementwise ones (fpgpu_mul ... fpgpu_pow), fpgpu_batch_inv and fpgpu_div
+ * stream their operands through the device in chunks -- copy in, kernels and
+ * copy out overlap, `out` may be `a` or `b`, and the arrays may exceed device
+ * memory (a batch inversion is cut into independent ranges: an inverse does not
+ * depend on the cut); the others hold whole operands in device memory they
+ * allocate and free themselves.  The library
  * keeps 72 MiB of pinned host memory, and 72 MiB on each device used this way,
  * until the process ends (FPGPU_COPY_THREADS = 6; 12 MiB each per thread).
  */

@@ -447,3 +447,43 @@ def test_double_and_div_by_2_on_handles_and_device_pointers(cpa, devices, ids):
         f.div_by_2_dev(ta, th)
         assert np.array_equal(td.cpu().numpy().view(np.uint64), o.double(ha))
         assert np.array_equal(th.cpu().numpy().view(np.uint64), o.div_by_2(ha))
+
+
+@pytest.mark.parametrize("threads", [0, 3])
+@pytest.mark.parametrize("name,n", [("bls12_381_fq", 300007), ("bn254_fr", 400003), ("goldilocks", 1500001), ("odd_composite_128", 333333)])
+def test_host_inversion_and_division_through_the_chunk_pipeline(cpa, tuning, threads, name, n):
+    """Above 4 MiB the host-buffer batch inversion and division run range by range through the chunk pipeline
+    (every chunk its own Montgomery trick on its lane's stream, flags coming back with the results).  Inverses
+    and flags must equal one inversion over the whole batch in HBM (handles) -- an inverse does not depend on
+    how the batch is cut -- and the oracle on both ends; zeros on chunk boundaries, and for the composite
+    modulus elements without an inverse (the poisoned-group fallback inside a chunk)."""
+    from oracle.fp_oracle import Oracle
+    if threads:
+        tuning("FPGPU_COPY_THREADS", threads)
+    g = load_golden(name)
+    p, n64 = h2i(g["modulus"]), g["n64"]
+    f, o = cpa.MontyField(p, n64), Oracle(p, n64)
+    V = cpa.DeviceVector
+    vx, va, vo = V.alloc(f, n).fill_random(41), V.alloc(f, n).fill_random(42), V.alloc(f, n)
+    x, a = vx.download(), va.download()
+    assert x.nbytes >= (4 << 20)
+    per_guess = (6 << 20) // (16 * n64 + 1)
+    for i in (0, 1, n - 1, n // 2, per_guess - 1, per_guess, 2 * per_guess + 5, 60000, 65536):
+        if i < n:
+            x[i] = 0
+    if name == "odd_composite_128":
+        x[77] = ints_to_array([3], n64)[0]
+        x[n - 5] = ints_to_array([9], n64)[0]
+    vx.upload(x)
+    want_flags = f.inv_vec(vx, vo)
+    want = vo.download()
+    got, flags = f.inv(x)
+    assert np.array_equal(flags, want_flags) and np.array_equal(got, want)
+    assert int(flags.sum()) >= 6
+    for sl in (slice(0, 400), slice(n - 400, n)):
+        oi, of = o.batch_inv(x[sl])
+        assert np.array_equal(got[sl], oi) and np.array_equal(flags[sl], of)
+    dflags = f.div_vec(va, vx, vo)
+    q, qflags = f.checked_div(a, x)
+    assert np.array_equal(qflags, dflags) and np.array_equal(q, vo.download()) and np.array_equal(qflags, want_flags)
+    assert np.array_equal(q[:400], o.mul(a[:400], want[:400]))
