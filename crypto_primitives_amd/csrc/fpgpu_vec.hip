@@ -525,6 +525,15 @@ int fpgpu_set_devices(const int* ids, int count) {
     }
     g_list = list;
     g_list_distinct = distinct;
+    // direct peer copies (fpgpu_vec_copy, the copy transport of the all-gather) between the list's devices:
+    // best effort -- without peer access hipMemcpyPeerAsync still works, staged by the runtime
+    for (Slot* a : g_list)
+        for (Slot* b : g_list) {
+            int can = 0;
+            if (a->device == b->device || hipSetDevice(a->device) != hipSuccess) continue;
+            if (hipDeviceCanAccessPeer(&can, a->device, b->device) == hipSuccess && can) (void)hipDeviceEnablePeerAccess(b->device, 0);
+            (void)hipGetLastError();   // "already enabled" included
+        }
     return FPGPU_OK;
 }
 
