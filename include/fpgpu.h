@@ -38,8 +38,8 @@
  * memory (a batch inversion is cut into independent ranges: an inverse does not
  * depend on the cut); the others hold whole operands in device memory they
  * allocate and free themselves.  The library
- * keeps 72 MiB of pinned host memory, and 72 MiB on each device used this way,
- * until the process ends (FPGPU_COPY_THREADS = 6; 12 MiB each per thread).
+ * keeps 48 MiB of pinned host memory, and 48 MiB on each device used this way,
+ * until the process ends (FPGPU_COPY_THREADS = 4; 12 MiB each per thread).
  */
 #ifndef FPGPU_H
 #define FPGPU_H
