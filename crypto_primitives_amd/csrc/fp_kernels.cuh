@@ -152,65 +152,53 @@ __global__ __launch_bounds__(kBlock) void k_fill_random(uint32_t* __restrict__ o
 //     (u, v) <- ( u f0 + v g0 ,  u f1 + v g1 ) / 2^30  mod p   (Montgomery step on 2^30)
 // with a = y u, b = y v (mod p) invariant, so b = gcd ends as 1 and v = y^-1 mod p.
 // ceil((2 len(p) - 1) / 30) + 2 rounds always suffice (extra rounds are no-ops); that is
-// 28 rounds of ~1.5k instructions for a 381-bit modulus, against 762 full-width steps of
+// 28 rounds of ~1.4k instructions for a 381-bit modulus, against 762 full-width steps of
 // ~270 instructions for the textbook loop (1.4 ms -> 0.36 ms -> this).
 // Returns false when gcd(y, p) != 1 (the reference's invert_odd_mod_vartime -> None).
-template <int N>
-__device__ __forceinline__ void mul_small(uint32_t (&r)[N + 1], uint32_t f, const uint32_t (&x)[N]) {
-    uint32_t c = 0;
-#pragma unroll
-    for (int j = 0; j < N; j++) {
-        uint64_t t = (uint64_t)f * x[j] + c;
-        r[j] = (uint32_t)t;
-        c = (uint32_t)(t >> 32);
-    }
-    r[N] = c;
-}
-template <int N>
-__device__ __forceinline__ void mac_small(uint32_t (&r)[N + 1], uint32_t f, const uint32_t (&x)[N]) {
-    uint32_t c = 0;
-#pragma unroll
-    for (int j = 0; j < N; j++) {
-        uint64_t t = (uint64_t)f * x[j] + r[j] + c;
-        r[j] = (uint32_t)t;
-        c = (uint32_t)(t >> 32);
-    }
-    r[N] += c;
-}
-// |x f + y g| / 2^30 for non-negative N-limb x, y and signed 31-bit f, g; returns true if
-// the signed value was negative.
+// The update factors of K = 30 divsteps satisfy |f| + |g| <= 2^30 (each step at most doubles the sum of a
+// row of the transition matrix), which is what bounds everything below.
+//
+// |x f + y g| / 2^30 for non-negative N-limb x, y; returns true if the signed value was negative.
+// x f + y g = +-(|f| x + s |g| y) with s = -1 where the signs differ: y is negated in two's complement on
+// N + 1 limbs, so one product-scanning pass -- two multiply-adds per limb into a 64-bit column, no carry
+// instruction -- yields the signed inner value modulo 2^(32 (N + 1)) (|inner| < 2^(32 N + 30) fits).
 template <int N>
 __device__ __forceinline__ bool bingcd_update_ab(uint32_t (&out)[N], const uint32_t (&x)[N], const uint32_t (&y)[N],
                                                  int32_t f, int32_t g) {
     const bool sf = f < 0, sg = g < 0;
     const uint32_t af = sf ? 0u - (uint32_t)f : (uint32_t)f, ag = sg ? 0u - (uint32_t)g : (uint32_t)g;
-    uint32_t P1[N + 1], P2[N + 1], S[N + 1], D[N + 1];
-    mul_small<N>(P1, af, x);
-    mul_small<N>(P2, ag, y);
-    add_limbs<N + 1>(S, P1, P2);
-    const uint32_t bo = sub_limbs<N + 1>(D, P1, P2);
-    // D = |P1 - P2|
-    const uint32_t nm = 0u - bo;
-    unsigned cy = bo;
+    const uint32_t nm = sf != sg ? ~0u : 0u;
+    uint32_t y2[N + 1], Z[N + 1];
+    unsigned cy = nm & 1u;
 #pragma unroll
-    for (int j = 0; j <= N; j++) D[j] = __builtin_addc(D[j] ^ nm, 0u, cy, &cy);
-    const bool same = sf == sg;
-    const uint32_t sm = same ? ~0u : 0u;
-    uint32_t mag[N + 1];
+    for (int j = 0; j < N; j++) y2[j] = __builtin_addc(y[j] ^ nm, 0u, cy, &cy);
+    y2[N] = __builtin_addc(nm, 0u, cy, &cy);   // the sign limb (0 again when y == 0)
+    uint64_t c = 0;
 #pragma unroll
-    for (int j = 0; j <= N; j++) mag[j] = (S[j] & sm) | (D[j] & ~sm);
+    for (int j = 0; j < N; j++) {
+        c = (c >> 32) + (uint64_t)af * x[j] + (uint64_t)ag * y2[j];   // < 2^32 + 2^62
+        Z[j] = (uint32_t)c;
+    }
+    c = (c >> 32) + (uint64_t)ag * y2[N];
+    Z[N] = (uint32_t)c;
+    const bool inner_neg = (Z[N] >> 31) != 0;
+    const uint32_t zm = inner_neg ? ~0u : 0u;
+    cy = zm & 1u;
 #pragma unroll
-    for (int j = 0; j < N; j++) out[j] = (mag[j] >> 30) | (mag[j + 1] << 2);
-    return same ? sf : (bo ? sg : sf);
+    for (int j = 0; j <= N; j++) Z[j] = __builtin_addc(Z[j] ^ zm, 0u, cy, &cy);
+#pragma unroll
+    for (int j = 0; j < N; j++) out[j] = (Z[j] >> 30) | (Z[j + 1] << 2);
+    return sf != inner_neg;
 }
-// (u f + v g) / 2^30 mod p for u, v in [0, p) and signed 31-bit f, g; result in [0, p).
+// (u f + v g) / 2^30 mod p for u, v in [0, p); result in [0, p).  A negative factor times u is the positive
+// factor times (p - u), so Z = |f| U + |g| V <= 2^30 p; q makes Z + q p divisible by 2^30 and
+// (Z + q p) / 2^30 < 2 p: one product-scanning pass of three multiply-adds per limb, one conditional subtraction.
 template <int N>
 __device__ __forceinline__ void bingcd_update_uv(uint32_t (&out)[N], const uint32_t (&u)[N], const uint32_t (&v)[N],
                                                  int32_t f, int32_t g, const uint32_t (&m)[N], uint32_t n0inv) {
     const bool sf = f < 0, sg = g < 0;
     const uint32_t af = sf ? 0u - (uint32_t)f : (uint32_t)f, ag = sg ? 0u - (uint32_t)g : (uint32_t)g;
     uint32_t U[N], V[N], t[N];
-    // a negative factor times u is the positive factor times (p - u)  (mod p)
     sub_limbs<N>(t, m, u);
     const uint32_t mf = sf ? ~0u : 0u, mg = sg ? ~0u : 0u;
 #pragma unroll
@@ -219,25 +207,25 @@ __device__ __forceinline__ void bingcd_update_uv(uint32_t (&out)[N], const uint3
 #pragma unroll
     for (int j = 0; j < N; j++) V[j] = (t[j] & mg) | (v[j] & ~mg);
     uint32_t Z[N + 1];
-    mul_small<N>(Z, af, U);
-    mac_small<N>(Z, ag, V);                              // Z < 2^31 p
-    const uint32_t q = (Z[0] * n0inv) & 0x3FFFFFFFu;     // makes Z + q p divisible by 2^30
-    mac_small<N>(Z, q, m);                               // Z < 2^32 p: still N + 1 limbs
+    uint64_t c = (uint64_t)af * U[0] + (uint64_t)ag * V[0];
+    const uint32_t q = ((uint32_t)c * n0inv) & 0x3FFFFFFFu;
+    c += (uint64_t)q * m[0];                                          // each product < 2^62
+    Z[0] = (uint32_t)c;
+#pragma unroll
+    for (int j = 1; j < N; j++) {
+        c = (c >> 32) + (uint64_t)af * U[j] + (uint64_t)ag * V[j] + (uint64_t)q * m[j];
+        Z[j] = (uint32_t)c;
+    }
+    Z[N] = (uint32_t)(c >> 32);
     uint32_t w[N + 1], d[N + 1], mm[N + 1];
 #pragma unroll
     for (int j = 0; j < N; j++) { w[j] = (Z[j] >> 30) | (Z[j + 1] << 2); mm[j] = m[j]; }
     w[N] = Z[N] >> 30;
     mm[N] = 0;
-    // w < 3p: subtract p while it fits (twice)
+    const uint32_t bo = sub_limbs<N + 1>(d, w, mm);   // w < 2p: subtract p if it fits
+    const uint32_t keep = 0u - bo;                     // all-ones: w < p, keep w
 #pragma unroll
-    for (int pass = 0; pass < 2; pass++) {
-        const uint32_t bo = sub_limbs<N + 1>(d, w, mm);
-        const uint32_t keep = 0u - bo;   // all-ones: w < p, keep w
-#pragma unroll
-        for (int j = 0; j <= N; j++) w[j] = (w[j] & keep) | (d[j] & ~keep);
-    }
-#pragma unroll
-    for (int j = 0; j < N; j++) out[j] = w[j];
+    for (int j = 0; j < N; j++) out[j] = (w[j] & keep) | (d[j] & ~keep);
 }
 
 template <int N>

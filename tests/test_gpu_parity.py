@@ -855,3 +855,31 @@ def test_pow_both_ladders_every_width(cpa, tuning, case, window):
     for e in exps:
         ebits = max(bits, 64 * ((e.bit_length() + 63) // 64))      # the exponent may be wider than the field
         assert np.array_equal(f.pow(x, e), o.pow(x, e, exponent_bits=ebits)), hex(e)
+
+
+@pytest.mark.parametrize("case", _UNSAT_MODULI + [("goldilocks", 2**64 - 2**32 + 1, 1), ("p127", 2**127 - 1, 2)], ids=lambda c: c[0])
+def test_exact_inversion_special_values(cpa, case):
+    """The exact inversion at the top of the batch inversion (binary GCD on word-sized approximations, update
+    factors applied in product-scanning passes whose bounds rely on |f| + |g| <= 2^30) on values that drive the
+    approximations and the updates to their extremes: powers of two and their neighbours, p minus those, small
+    numbers, (p +- 1) / 2.  A batch of one element makes the top level invert that element itself; a batch of
+    all of them checks the same values inside chains."""
+    from oracle.fp_oracle import Oracle
+    _, p, n64 = case
+    f, o = cpa.MontyField(p, n64), Oracle(p, n64)
+    bits = p.bit_length()
+    vals = {1, 2, 3, 5, p - 1, p - 2, p - 3, (p - 1) // 2, (p + 1) // 2, (p - 1) // 2 - 1}
+    for k in range(1, bits):
+        for d in (-1, 0, 1):
+            for v in ((1 << k) + d, p - (1 << k) + d):
+                if 0 < v < p:
+                    vals.add(v)
+    vals = sorted(vals)
+    x = ints_to_array(vals, n64)
+    want, wflags = o.batch_inv(x)
+    got, flags = f.inv(x)
+    assert np.array_equal(flags, wflags) and np.array_equal(got, want)
+    step = max(1, len(vals) // 120)
+    for i in range(0, len(vals), step):
+        g1, f1 = f.inv(x[i:i + 1])
+        assert np.array_equal(g1, want[i:i + 1]) and f1[0] == wflags[i], hex(vals[i])
