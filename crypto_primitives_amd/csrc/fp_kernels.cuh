@@ -266,22 +266,29 @@ __device__ __forceinline__ bool inv_bingcd(uint32_t (&out)[N], const uint32_t (&
         uint64_t bbar = wide ? ((tb << 30) | (b[0] & 0x3FFFFFFFu)) : (((uint64_t)b[1] << 32) | b[0]);
         // ---- K divsteps on the approximations
         uint32_t f0 = 1, g0 = 0, f1 = 0, g1 = 1;   // two's complement, |.| <= 2^30
+        // One 32-bit mask per decision, applied to both halves of a, b with bit-field inserts.  The swap mask
+        // comes out of a three-instruction asm so that the compiler keeps it a VGPR mask (seen through, the
+        // comparison turns every select below into a v_cndmask on an SGPR pair and the masks are built twice).
 #pragma unroll 2
         for (int i = 0; i < K; i++) {
-            const uint64_t odd = 0ull - (abar & 1ull);
-            const uint64_t lt = abar < bbar ? ~0ull : 0ull;
-            const uint64_t sw = odd & lt;
-            const uint64_t tx = (abar ^ bbar) & sw;
-            abar ^= tx; bbar ^= tx;
-            const uint32_t sw32 = (uint32_t)sw, odd32 = (uint32_t)odd;
-            const uint32_t tf = (f0 ^ f1) & sw32, tg = (g0 ^ g1) & sw32;
-            f0 ^= tf; f1 ^= tf; g0 ^= tg; g1 ^= tg;
-            abar -= bbar & odd;
-            f0 -= f1 & odd32;
-            g0 -= g1 & odd32;
-            abar >>= 1;
-            f1 <<= 1;
-            g1 <<= 1;
+            const uint32_t oddm = 0u - ((uint32_t)abar & 1u);
+            uint32_t swm;
+            asm("v_cmp_lt_u64 vcc, %1, %2\n\ts_nop 1\n\tv_cndmask_b32 %0, 0, %3, vcc" : "=v"(swm) : "v"(abar), "v"(bbar), "v"(oddm) : "vcc");
+            const uint32_t alo = (uint32_t)abar, ahi = (uint32_t)(abar >> 32), blo = (uint32_t)bbar, bhi = (uint32_t)(bbar >> 32);
+            const uint32_t nalo = (blo & swm) | (alo & ~swm), nahi = (bhi & swm) | (ahi & ~swm);
+            uint32_t nblo = (alo & swm) | (blo & ~swm), nbhi = (ahi & swm) | (bhi & ~swm);
+            uint32_t nf0 = (f1 & swm) | (f0 & ~swm), nf1 = (f0 & swm) | (f1 & ~swm);
+            uint32_t ng0 = (g1 & swm) | (g0 & ~swm), ng1 = (g0 & swm) | (g1 & ~swm);
+            asm("" : "+v"(nblo), "+v"(nbhi), "+v"(nf1), "+v"(ng1));   // keep the selected values as they are (no re-expansion into the masks)
+            bbar = ((uint64_t)nbhi << 32) | nblo;
+            unsigned bo = 0;
+            const uint32_t dlo = __builtin_subc(nalo, nblo & oddm, bo, &bo);
+            const uint32_t dhi = __builtin_subc(nahi, nbhi & oddm, bo, &bo);
+            abar = (((uint64_t)dhi << 32) | dlo) >> 1;
+            f0 = nf0 - (nf1 & oddm);
+            g0 = ng0 - (ng1 & oddm);
+            f1 = nf1 << 1;
+            g1 = ng1 << 1;
         }
         // ---- apply to the full-width values
         uint32_t na[N], nb[N], nu[N], nv[N];
