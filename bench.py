@@ -32,9 +32,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-MFMA_I8_PEAK_TOPS = 5000.0      # INFERRED, not a guide figure: 2x the ~2.5 PFLOP/s dense bf16 peak of MI355X_MICROARCH.md
-MFMA_I8_PEAK_NOTE = ("int8 peak is inferred as 2x the guide's ~2.5 PFLOP/s dense bf16 figure (the guide lists no int8 "
-                     "number); measured bare v_mfma_i32_16x16x64_i8 loop: 8.4 ns per MFMA per SIMD = 3.99 POP/s")
+MFMA_I8_PEAK_TOPS = 5000.0      # MI355X_MICROARCH.md matrix-core table: I8 16x16x64 / 32x32x32 = 2x BF16 per clock; dense bf16 ~2.5 PFLOP/s
+MFMA_I8_PEAK_NOTE = ("int8 peak = 2x the guide's ~2.5 PFLOP/s dense bf16 figure (its matrix-core table: I8 runs at the cycles "
+                     "of the BF16 form at 2x the K, i.e. 2x BF16 per clock); measured bare v_mfma_i32_16x16x64_i8 loop: "
+                     "8.4 ns per MFMA per SIMD = 3.99 POP/s")
 VALU_MAD_PEAK_TOPS = 39.3       # 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz v_mad_u64_u32 lane-ops/s (measured 36.5)
 
 
@@ -52,11 +53,51 @@ def parse():
     ap.add_argument("--inv-log2", type=int, default=24, help="batch inversion over 2^k elements in total")
     ap.add_argument("--force-dist", action="store_true",
                     help="take the multi-rank code path (RCCL process group, all-gather, max over ranks) even at world size 1")
+    ap.add_argument("--dry-run-launch", action="store_true",
+                    help="with --gpus N > 1 and no WORLD_SIZE: print the torch.distributed.run command instead of running it")
+    ap.add_argument("--sharded-devices", default=None,
+                    help="device list of the in-library sharded measurement (extra.in_library_sharded), e.g. 0,0,0,0,0,0,0,0 to "
+                         "rehearse eight parts on one GPU; default: 0..N-1")
+    ap.add_argument("--no-sharded", action="store_true", help="skip extra.in_library_sharded")
     return ap.parse_args()
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` invoked bare (no WORLD_SIZE) for N > 1: start the N ranks as a FRESH child process
+    under torch.distributed.run (this process has not touched HIP and never replaces itself), relay the child's
+    one JSON line and its return code."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:   # a free rendezvous port on the loopback interface
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    argv = [a for a in sys.argv[1:] if a != "--dry-run-launch"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus,
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    if args.dry_run_launch:
+        print(json.dumps({"would_launch": cmd}), flush=True)
+        return 0
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL between processes needs it on these hosts
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if line is not None:
+        print(line, flush=True)
+    elif proc.returncode == 0:
+        print("bench.py: the launched ranks printed no result line", file=sys.stderr)
+        return 1
+    return proc.returncode
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -66,9 +107,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    if world != args.gpus and rank == 0:   # the launcher's world size is what runs; say so, do not die on it
+        print("bench.py: --gpus %d but WORLD_SIZE=%d: measuring %d rank(s)" % (args.gpus, world, world), file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
     torch.cuda.set_device(local_rank)
@@ -217,6 +257,23 @@ def main():
         extra["pow_bn254"] = bench_pow(f, a, out, time_steps)
         if rank == 0:
             extra["drop_in_chain_bn254"] = bench_drop_in_chain(f)
+
+    # ---------------- one process, every GPU, inside the C ABI ----------
+    # The survey's own multi-GPU design: ONE process names the devices (fpgpu_set_devices), its vectors are
+    # sharded / replicated handles, one host thread enqueues on every device's stream and RCCL
+    # (ncclCommInitAll) gathers the mat-vec's row blocks.  Rank 0 drives all `world` GPUs once every rank has
+    # released its memory; a failure here is reported in the block, it never costs the bench line.
+    if not args.no_extra and not args.no_sharded:
+        a = b = out = None
+        ops.clear()
+        torch.cuda.empty_cache()
+        barrier()
+        if rank == 0:
+            devs = [int(t) for t in args.sharded_devices.split(",")] if args.sharded_devices else list(range(world))
+            try:
+                extra["in_library_sharded"] = bench_in_library_sharded(devs)
+            except Exception as exc:   # noqa: BLE001 - first contact with several physical GPUs happens on the driver's node
+                extra["in_library_sharded"] = {"devices": devs, "error": "%s: %s" % (type(exc).__name__, exc)}
 
     # ---------------- CPU baseline (rank 0, N = 1 only) --------------------------------
     cpu = None
@@ -421,6 +478,78 @@ def bench_matvec(args, f, world, rank, distributed, time_steps, primary, samples
                             "traffic_source": _pmc_traffic("matvec", "rows", rows)[1],
                             "kernel": "k_matvec_mfma<8,4> (+ k_mv_expand, k_mv_finish)"},
                "verified_vs_oracle": None}
+    return res
+
+
+def bench_in_library_sharded(devices, steps=5, warmup=2):
+    """SURVEY.md 8e as written: a single process drives `devices` through the C ABI -- fpgpu_set_devices,
+    FPGPU_PLACE_SHARDED / FPGPU_PLACE_REPLICATED handles, one stream per list entry, no torch.distributed.
+    Elementwise mul (2^26 BN254 elements per entry, weak) and batch inversion (2^24 BLS12-381 elements in total)
+    shard with no collective; the 2^15 x 2^15 mat-vec shards rows (the reference's rayon axis,
+    src/matrix.rs:170-184), x replicated, and is timed twice: y left row-sharded, and y replicated, i.e. with the
+    all-gather of the row blocks (ncclAllGather over the communicators of ncclCommInitAll; event-ordered peer
+    copies when the list repeats a device) -- the difference is the collective's cost.  Wall time on the host
+    around `steps` calls, every device synchronised at both ends."""
+    import numpy as np
+    import crypto_primitives_amd as cpa
+    from crypto_primitives_amd import vec as V
+    g = len(devices)
+    res = {"devices": list(devices), "process": "one process, one host thread, one stream per list entry",
+           "transport": "RCCL ncclAllGather (ncclCommInitAll)" if len(set(devices)) == g and g > 1 else
+                        ("none (one entry)" if g == 1 else "event-ordered peer copies (the list repeats a device; RCCL refuses that)")}
+
+    def timed(fn, sync):
+        for _ in range(warmup):
+            fn()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        sync()
+        return (time.perf_counter() - t0) / steps
+
+    V.set_devices(devices)
+    try:
+        f = cpa.MontyField(cpa.BN254_FR, 4)
+        n = (1 << 26) * g
+        va = V.DeviceVector.alloc(f, n, V.PLACE_SHARDED).fill_random(0x51)
+        vb = V.DeviceVector.alloc(f, n, V.PLACE_SHARDED).fill_random(0x52)
+        vo = V.DeviceVector.alloc(f, n, V.PLACE_SHARDED)
+        dt = timed(lambda: f.mul_vec(va, vb, vo), vo.sync)
+        res["mul_bn254"] = {"elements_total": n, "ms": dt * 1e3, "Gmul_per_s": n / dt / 1e9,
+                            "hbm_frac_per_device_entry": 96.0 * n / dt / 1e9 / HBM_PEAK_GBPS / len(set(devices))}
+        for v in (va, vb, vo):
+            v.free()
+
+        fq = cpa.MontyField(cpa.BLS12_381_FQ, 6)
+        n = 1 << 24
+        vx = V.DeviceVector.alloc(fq, n, V.PLACE_SHARDED).fill_random(0x53)
+        vi = V.DeviceVector.alloc(fq, n, V.PLACE_SHARDED)
+        vc = V.DeviceVector.alloc(fq, n, V.PLACE_SHARDED)
+        dt = timed(lambda: fq.inv_vec(vx, vi, want_flags=False), vi.sync)
+        fq.mul_vec(vx, vi, vc)
+        prod = vc.download(0, 4096)
+        res["batch_inv_bls12_381"] = {"elements_total": n, "ms": dt * 1e3, "Ginv_per_s": n / dt / 1e9,
+                                      "x_times_inv_is_one_on_sample": bool(np.array_equal(prod, np.broadcast_to(fq.one_words, prod.shape)))}
+        for v in (vx, vi, vc):
+            v.free()
+
+        dim = 1 << 15
+        A = V.DeviceVector.alloc_rows(f, dim, dim, V.PLACE_SHARDED).fill_random(0x54)
+        x = V.DeviceVector.alloc(f, dim, V.PLACE_REPLICATED).fill_random(0x55)
+        ys = V.DeviceVector.alloc(f, dim, V.PLACE_SHARDED)
+        yr = V.DeviceVector.alloc(f, dim, V.PLACE_REPLICATED)
+        t_sh = timed(lambda: f.matvec_vec(A, dim, dim, x, ys), ys.sync)
+        t_rep = timed(lambda: f.matvec_vec(A, dim, dim, x, yr), yr.sync)
+        same = bool(np.array_equal(ys.download(), yr.download()))
+        res["matvec_bn254"] = {"dim": dim, "ms_y_row_sharded": t_sh * 1e3, "ms_y_replicated_with_allgather": t_rep * 1e3,
+                               "allgather_ms": (t_rep - t_sh) * 1e3, "allgather_bytes_per_entry": 32 * dim // g,
+                               "matrix_elems_per_s": dim * dim / t_rep, "gathered_equals_sharded": same,
+                               "hbm_GBps_total": 32.0 * (dim * dim + dim + dim) / t_sh / 1e9}
+        for v in (A, x, ys, yr):
+            v.free()
+    finally:
+        V.set_devices([])
     return res
 
 

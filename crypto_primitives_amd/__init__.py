@@ -5,7 +5,7 @@ config interface.  (The directory is importable as `crypto_primitives_amd`; the
 hyphenated name `crypto-primitives_amd` is not a valid Python identifier.)"""
 from ._lib import FpgpuError, LIB_PATH, load  # noqa: F401
 from .field import InvalidModulus, MontyField  # noqa: F401
-from .vec import DeviceIndices, DeviceVector, PLACE_CURRENT, PLACE_REPLICATED, PLACE_SHARDED, get_devices, set_devices  # noqa: F401
+from .vec import DeviceIndices, DeviceSet, DeviceVector, PLACE_CURRENT, PLACE_REPLICATED, PLACE_SHARDED, get_devices, set_devices  # noqa: F401
 
 # Moduli named in BASELINE.json's configs.
 BN254_FR = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001

@@ -69,6 +69,12 @@ SIGNATURES = {
     "fpgpu_dot": (_int, [_vp, _vp, _vp, _sz, _vp]),
     "fpgpu_set_devices": (_int, [_c.POINTER(_int), _int]),
     "fpgpu_get_devices": (_int, [_c.POINTER(_int), _int]),
+    "fpgpu_devset_create": (_int, [_c.POINTER(_int), _int, _c.POINTER(_vp)]),
+    "fpgpu_devset_destroy": (None, [_vp]),
+    "fpgpu_devset_devices": (_int, [_vp, _c.POINTER(_int), _int]),
+    "fpgpu_vec_alloc_on": (_int, [_vp, _vp, _sz, _int, _c.POINTER(_vp)]),
+    "fpgpu_vec_alloc_rows_on": (_int, [_vp, _vp, _sz, _sz, _int, _c.POINTER(_vp)]),
+    "fpgpu_idx_alloc_rows_on": (_int, [_vp, _sz, _sz, _int, _c.POINTER(_vp)]),
     "fpgpu_vec_alloc": (_int, [_vp, _sz, _int, _c.POINTER(_vp)]),
     "fpgpu_vec_alloc_rows": (_int, [_vp, _sz, _sz, _int, _c.POINTER(_vp)]),
     "fpgpu_vec_free": (None, [_vp]),

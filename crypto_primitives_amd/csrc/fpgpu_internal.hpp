@@ -19,6 +19,17 @@ int hip_fail(hipError_t e, const char* what);     // FPGPU_ERR_HIP with the runt
 // (fpgpu_stage.hip); both return when the host buffer is the caller's again / holds the data.
 int upload_staged(void* dev, const void* host, size_t bytes, hipStream_t stream);
 int download_staged(void* host, const void* dev, size_t bytes, hipStream_t stream);
+// The same for several ranges at once, each with its own device and stream (the parts of a sharded or
+// replicated vector): ranges on different devices are in flight together, every device over its own link.
+struct CopySeg {
+    int device;
+    void* dev;
+    void* host;   // read by an upload, written by a download
+    size_t bytes;
+    hipStream_t stream;
+};
+int upload_staged_multi(const CopySeg* segs, size_t count);
+int download_staged_multi(const CopySeg* segs, size_t count);
 // out[i] = op(a[i], b[i]) on host arrays of n elements of esz bytes (b may be NULL): `call` queues the
 // operation for `count` elements in device memory on `stream`.  Chunked, full duplex, no allocation per
 // call above 4 MiB; synchronous.

@@ -24,8 +24,11 @@
 #include <atomic>
 #include <condition_variable>
 #include <cstring>
+#include <deque>
 #include <functional>
 #include <mutex>
+#include <new>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -35,65 +38,60 @@ namespace fpgpu {
 
 namespace {
 
-// ---- persistent host threads: run(parts, fn) calls fn(0) here and fn(1..parts-1) on workers ----------
-class WorkerPool {
+// ---- host threads: a queue of independent tasks, grown on demand, never torn down ------------------
+class TaskPool {
    public:
-    explicit WorkerPool(int workers) {
-        for (int i = 0; i < workers; i++) threads_.emplace_back([this] { loop(); });
+    // grows the pool towards `n` threads; returns how many there are (a thread that cannot be created --
+    // EAGAIN, RLIMIT_NPROC -- is simply not there: callers size their lane sets by the return value)
+    int ensure(int n) {
+        std::lock_guard<std::mutex> l(mu_);
+        while ((int)threads_.size() < n) {
+            try {
+                threads_.emplace_back([this] { loop(); });
+            } catch (const std::exception&) {
+                break;
+            }
+        }
+        return (int)threads_.size();
     }
-    ~WorkerPool() {
+    void submit(std::function<void()> fn) {
         {
             std::lock_guard<std::mutex> l(mu_);
-            stop_ = true;
+            q_.push_back(std::move(fn));
         }
-        cv_.notify_all();
-        for (auto& t : threads_) t.join();
-    }
-    int width() const { return (int)threads_.size() + 1; }
-    void run(int parts, const std::function<void(int)>& fn) {   // parts <= width(), checked by the caller
-        if (parts <= 1) {
-            fn(0);
-            return;
-        }
-        {
-            std::lock_guard<std::mutex> l(mu_);
-            fn_ = &fn;
-            next_ = 1;
-            parts_ = parts;
-            pending_ = parts - 1;
-        }
-        cv_.notify_all();
-        fn(0);
-        std::unique_lock<std::mutex> l(mu_);
-        done_.wait(l, [this] { return pending_ == 0; });
-        fn_ = nullptr;
+        cv_.notify_one();
     }
 
    private:
     void loop() {
         for (;;) {
-            int part;
-            const std::function<void(int)>* fn;
+            std::function<void()> fn;
             {
                 std::unique_lock<std::mutex> l(mu_);
-                cv_.wait(l, [this] { return stop_ || (fn_ && next_ < parts_); });
-                if (stop_) return;
-                part = next_++;
-                fn = fn_;
+                cv_.wait(l, [this] { return !q_.empty(); });
+                fn = std::move(q_.front());
+                q_.pop_front();
             }
-            (*fn)(part);
-            {
-                std::lock_guard<std::mutex> l(mu_);
-                if (--pending_ == 0) done_.notify_all();
-            }
+            fn();
         }
     }
     std::vector<std::thread> threads_;
     std::mutex mu_;
-    std::condition_variable cv_, done_;
-    const std::function<void(int)>* fn_ = nullptr;
-    int next_ = 0, parts_ = 0, pending_ = 0;
-    bool stop_ = false;
+    std::condition_variable cv_;
+    std::deque<std::function<void()>> q_;
+};
+struct Join {
+    std::mutex mu;
+    std::condition_variable cv;
+    int pending = 0;
+    void done() {
+        std::lock_guard<std::mutex> l(mu);
+        if (--pending == 0) cv.notify_all();
+    }
+    void wait() {
+        std::unique_lock<std::mutex> l(mu);
+        cv.wait(l, [this] { return pending == 0; });
+    }
 };
 
 constexpr size_t kLaneChunk = (size_t)2 << 20;   // bytes per operand per pipeline slot
@@ -103,32 +101,46 @@ constexpr size_t kDownChunk = kLaneChunk;        // plain downloads: small chunk
 constexpr size_t kMinStaged = (size_t)4 << 20;   // below this a plain hipMemcpy is as fast
 constexpr int kMaxLanes = 16;
 
-struct Lane {
-    hipStream_t stream = nullptr;                  // copies from the device
+// A lane is the unit a transfer owns while it runs: two pinned buffers (portable: usable with every
+// device) and, per device it has worked with, a stream, events and the device halves of its pipeline
+// slots.  Lanes are handed out from one process-wide table, so independent host threads -- the
+// reference's configs are Send + Sync and shared across rayon workers (src/lib.rs:62-65) -- run their
+// staged transfers side by side, each on its own lanes; a transfer that finds every lane taken waits for
+// the first one to come back.
+struct LaneDev {
+    int device = -1;
+    hipStream_t stream = nullptr;                  // copies from the device; lane-local kernels
     hipEvent_t ev[2] = {nullptr, nullptr};         // slot s: its last DMA is through
     hipEvent_t uploaded[2] = {nullptr, nullptr};   // slot s: its operands are on the device
     hipEvent_t computed[2] = {nullptr, nullptr};   // slot s: its kernel is through
-    char* dev[2] = {nullptr, nullptr};   // kSlotBytes each, on this device (elementwise pipeline only)
+    hipEvent_t order = nullptr;                    // "everything queued on the caller's stream so far"
+    char* dev[2] = {nullptr, nullptr};             // kSlotBytes each (elementwise pipeline only)
 };
-struct DeviceLanes {
+struct Lane {
+    char* pin[2] = {nullptr, nullptr};   // kSlotBytes each
+    std::vector<LaneDev*> devs;          // touched only by the transfer that holds the lane
+    bool busy = false;
+    bool dead = false;                   // its pinned buffers could not be had
+};
+struct DeviceShared {
     int device = -1;
-    hipEvent_t order = nullptr;   // "everything queued on the caller's stream so far"
-    hipStream_t up = nullptr;     // every copy to the device -- see the header
+    hipStream_t up = nullptr;        // every copy to the device -- see the header
     hipStream_t compute = nullptr;   // the pipeline's kernels (on `up` they would hold back the next copy)
-    std::mutex issue;             // one lane at a time queues on `up` (keeps a slot's commands together)
-    std::vector<Lane> lanes;
+    std::mutex issue;                // one lane at a time queues on `up` (keeps a slot's commands together)
 };
 struct Stage {
-    std::mutex mu;   // one staged transfer at a time: the pinned buffers and the lanes are shared
-    WorkerPool* pool = nullptr;
-    char* pin[kMaxLanes][2] = {};   // kSlotBytes each, portable: every device's lane t uses pin[t]
-    int pinned_lanes = 0;
-    std::vector<DeviceLanes*> devices;
+    std::mutex mu;                   // the lane table and the device table; never held across a transfer
+    std::condition_variable freed;
+    Lane lanes[kMaxLanes];
+    int waiters = 0;
+    bool host_unavailable = false;   // no pinned memory to be had: plain copies from now on
+    std::vector<DeviceShared*> devices;
+    TaskPool* pool = nullptr;
 };
 Stage g_stage;   // never torn down: the threads, buffers and streams live until the process ends
 
-// how many lanes a transfer uses: FPGPU_COPY_THREADS, else by the host's core count (measured on the
-// MI355X boxes, fpgpu_mul over 2^22 BN254 elements -- see DESIGN.md section 6)
+// how many lanes a transfer to ONE device asks for: FPGPU_COPY_THREADS, else by the host's core count
+// (measured on the MI355X boxes, fpgpu_mul over 2^22 BN254 elements -- see DESIGN.md section 6)
 int lanes_wanted() {
     long t = tuning().copy_threads;
     if (t <= 0) {
@@ -138,47 +150,132 @@ int lanes_wanted() {
     return (int)std::min<long>(t, kMaxLanes);
 }
 
-// the current device's lanes, grown to `lanes` (caller holds g_stage.mu)
-int acquire(int lanes, DeviceLanes** out) {
-    int dev = 0;
-    HIP_TRY(hipGetDevice(&dev));
-    DeviceLanes* d = nullptr;
+struct DeviceGuard {  // restores the caller's current device
+    int prev = -1;
+    DeviceGuard() {
+        if (hipGetDevice(&prev) != hipSuccess) {
+            (void)hipGetLastError();
+            prev = -1;
+        }
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+// The lanes one transfer holds; given back when it goes out of scope.
+struct LaneSet {
+    std::vector<Lane*> lanes;
+    ~LaneSet() {
+        if (lanes.empty()) return;
+        {
+            std::lock_guard<std::mutex> l(g_stage.mu);
+            for (Lane* L : lanes) L->busy = false;
+        }
+        g_stage.freed.notify_all();
+    }
+    int width() const { return (int)lanes.size(); }
+};
+
+// Takes up to `want` free lanes (at least one; waits while every lane is taken, and leaves a share for
+// the transfers waiting beside it).  FPGPU_ERR_UNSUPPORTED: staging is not available in this process
+// (no pinned memory) -- the caller takes the plain path.
+int acquire_lanes(int want, LaneSet* out) {
+    std::unique_lock<std::mutex> l(g_stage.mu);
+    if (!g_stage.pool) g_stage.pool = new (std::nothrow) TaskPool();
+    if (!g_stage.pool) return FPGPU_ERR_UNSUPPORTED;
+    auto free_lanes = [] {
+        int f = 0;
+        for (Lane& L : g_stage.lanes) f += !L.busy && !L.dead;
+        return f;
+    };
+    for (;;) {
+        if (g_stage.host_unavailable) return FPGPU_ERR_UNSUPPORTED;
+        g_stage.waiters++;
+        g_stage.freed.wait(l, [&] { return free_lanes() > 0 || g_stage.host_unavailable; });
+        g_stage.waiters--;
+        if (g_stage.host_unavailable) return FPGPU_ERR_UNSUPPORTED;
+        int take = std::min(want, std::max(1, free_lanes() / (g_stage.waiters + 1)));
+        // lanes beyond the caller's own need a thread each; without one (thread creation refused) the caller's does it all
+        int busy = 0;
+        for (Lane& L : g_stage.lanes) busy += L.busy;
+        if (g_stage.pool->ensure(std::min(kMaxLanes - 1, busy + take - 1)) == 0) take = 1;
+        for (Lane& L : g_stage.lanes) {
+            if ((int)out->lanes.size() == take) break;
+            if (L.busy || L.dead) continue;
+            for (int s = 0; s < 2 && !L.dead; s++)
+                if (!L.pin[s] && hipHostMalloc((void**)&L.pin[s], kSlotBytes, hipHostMallocPortable) != hipSuccess) {
+                    (void)hipGetLastError();
+                    L.pin[s] = nullptr;
+                    L.dead = true;   // a locked-memory limit: the table ends at the lanes that have their buffers
+                }
+            if (L.dead) {
+                for (Lane& M : g_stage.lanes)
+                    if (!M.pin[0] || !M.pin[1]) M.dead = true;
+                break;
+            }
+            L.busy = true;
+            out->lanes.push_back(&L);
+        }
+        if (!out->lanes.empty()) return FPGPU_OK;
+        bool any = false;
+        for (Lane& L : g_stage.lanes) any = any || !L.dead;
+        if (!any) {   // not even one lane's buffers: a host-side limit, so for good
+            g_stage.host_unavailable = true;
+            g_stage.freed.notify_all();
+            return FPGPU_ERR_UNSUPPORTED;
+        }
+        // every lane that exists is taken: wait for one
+    }
+}
+
+int device_shared(int device, DeviceShared** out) {   // `device` must be current
+    std::lock_guard<std::mutex> l(g_stage.mu);
+    DeviceShared* d = nullptr;
     for (auto* c : g_stage.devices)
-        if (c->device == dev) d = c;
+        if (c->device == device) d = c;
     if (!d) {
-        d = new DeviceLanes();
-        d->device = dev;
+        d = new (std::nothrow) DeviceShared();
+        if (!d) return fail(FPGPU_ERR_HIP, "out of host memory");
+        d->device = device;
         g_stage.devices.push_back(d);   // kept even if a creation below fails: the next call completes it
     }
-    if (!d->order) HIP_TRY(hipEventCreateWithFlags(&d->order, hipEventDisableTiming));
     if (!d->up) HIP_TRY(hipStreamCreateWithFlags(&d->up, hipStreamNonBlocking));
     if (!d->compute) HIP_TRY(hipStreamCreateWithFlags(&d->compute, hipStreamNonBlocking));
-    for (; g_stage.pinned_lanes < lanes; g_stage.pinned_lanes++)
-        for (int s = 0; s < 2; s++)
-            HIP_TRY(hipHostMalloc((void**)&g_stage.pin[g_stage.pinned_lanes][s], kSlotBytes, hipHostMallocPortable));
-    while ((int)d->lanes.size() < lanes) {
-        Lane l;
-        HIP_TRY(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
-        for (int s = 0; s < 2; s++) {
-            HIP_TRY(hipEventCreateWithFlags(&l.ev[s], hipEventDisableTiming));
-            HIP_TRY(hipEventCreateWithFlags(&l.uploaded[s], hipEventDisableTiming));
-            HIP_TRY(hipEventCreateWithFlags(&l.computed[s], hipEventDisableTiming));
-        }
-        d->lanes.push_back(l);
-    }
-    if (!g_stage.pool || g_stage.pool->width() < lanes) {
-        delete g_stage.pool;
-        g_stage.pool = new WorkerPool(lanes - 1);
-    }
     *out = d;
     return FPGPU_OK;
 }
 
-int ensure_device_slots(DeviceLanes* d, int lanes) {
-    for (int t = 0; t < lanes; t++)
-        for (int s = 0; s < 2; s++)
-            if (!d->lanes[t].dev[s]) HIP_TRY(hipMalloc((void**)&d->lanes[t].dev[s], kSlotBytes));
+int lane_dev(Lane* L, int device, LaneDev** out) {   // `device` must be current; the caller holds the lane
+    LaneDev* d = nullptr;
+    for (LaneDev* c : L->devs)
+        if (c->device == device) d = c;
+    if (!d) {
+        d = new (std::nothrow) LaneDev();
+        if (!d) return fail(FPGPU_ERR_HIP, "out of host memory");
+        d->device = device;
+        L->devs.push_back(d);
+    }
+    if (!d->stream) HIP_TRY(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
+    if (!d->order) HIP_TRY(hipEventCreateWithFlags(&d->order, hipEventDisableTiming));
+    for (int s = 0; s < 2; s++) {
+        if (!d->ev[s]) HIP_TRY(hipEventCreateWithFlags(&d->ev[s], hipEventDisableTiming));
+        if (!d->uploaded[s]) HIP_TRY(hipEventCreateWithFlags(&d->uploaded[s], hipEventDisableTiming));
+        if (!d->computed[s]) HIP_TRY(hipEventCreateWithFlags(&d->computed[s], hipEventDisableTiming));
+    }
+    *out = d;
     return FPGPU_OK;
+}
+LaneDev* lane_dev_made(Lane* L, int device) {   // after lane_dev succeeded for (L, device)
+    for (LaneDev* c : L->devs)
+        if (c->device == device) return c;
+    return nullptr;
+}
+DeviceShared* device_shared_made(int device) {
+    std::lock_guard<std::mutex> l(g_stage.mu);
+    for (auto* c : g_stage.devices)
+        if (c->device == device) return c;
+    return nullptr;
 }
 
 // A lane's failure reaches the calling thread (the message of fail() is thread-local).
@@ -197,69 +294,198 @@ struct LaneStatus {
     int result() { return code == FPGPU_OK ? FPGPU_OK : fail(code, msg); }
 };
 
-// Runs body(lane index) on `lanes` threads, each with `device` current; a failing lane drains its
-// stream before it returns so that no DMA is left running on the shared buffers.
+// Runs body(t) for every lane t of the set: lane 0 on the calling thread, the others on pool threads.
+// A body sets its own current device.
 template <typename Body>
-int run_lanes(DeviceLanes* d, int lanes, Body&& body) {
-    if (g_stage.pool->width() < lanes || (int)d->lanes.size() < lanes)   // every lane owns chunks: none may be missing
-        return fail(FPGPU_ERR_HIP, "staging: fewer copy threads than lanes");
+int run_lanes(const LaneSet& set, Body&& body) {
+    const int T = set.width();
     LaneStatus st;
-    g_stage.pool->run(lanes, [&](int t) {
-        int rc = FPGPU_OK;
-        hipError_t e = t == 0 ? hipSuccess : hipSetDevice(d->device);   // part 0 is the calling thread
-        if (e != hipSuccess) rc = hip_fail(e, "hipSetDevice");
-        if (rc == FPGPU_OK) rc = body(t);
-        if (rc != FPGPU_OK) {
-            (void)hipStreamSynchronize(d->up);
-            (void)hipStreamSynchronize(d->compute);
-            (void)hipStreamSynchronize(d->lanes[t].stream);
-        }
-        st.note(rc);
-    });
+    Join join;
+    join.pending = T - 1;
+    for (int t = 1; t < T; t++)
+        g_stage.pool->submit([&, t] {
+            st.note(body(t));
+            join.done();
+        });
+    st.note(body(0));
+    join.wait();
     return st.result();
 }
 
-inline size_t lane_chunks(size_t chunks, int t, int T) { return chunks > (size_t)t ? (chunks - t + T - 1) / T : 0; }
-
-int lane_upload(DeviceLanes* d, int t, int T, char* dev, const char* host, size_t bytes) {
-    Lane& L = d->lanes[t];
-    const size_t mine = lane_chunks((bytes + kUpChunk - 1) / kUpChunk, t, T);
-    for (size_t j = 0; j < mine; j++) {
-        const int s = (int)(j & 1);
-        const size_t off = (t + j * T) * kUpChunk, sz = std::min(kUpChunk, bytes - off);
-        if (j >= 2) HIP_TRY(hipEventSynchronize(L.ev[s]));   // the DMA out of this buffer is through
-        std::memcpy(g_stage.pin[t][s], host + off, sz);
-        std::lock_guard<std::mutex> issue(d->issue);
-        HIP_TRY(hipMemcpyAsync(dev + off, g_stage.pin[t][s], sz, hipMemcpyHostToDevice, d->up));
-        HIP_TRY(hipEventRecord(L.ev[s], d->up));
+// after a failed transfer: nothing may still be reading or writing the lanes' buffers when they go back
+void drain(const LaneSet& set, const std::vector<int>& devices) {
+    for (int dev : devices) {
+        if (hipSetDevice(dev) != hipSuccess) continue;
+        if (DeviceShared* ds = device_shared_made(dev)) {
+            if (ds->up) (void)hipStreamSynchronize(ds->up);
+            if (ds->compute) (void)hipStreamSynchronize(ds->compute);
+        }
+        for (Lane* L : set.lanes)
+            if (LaneDev* ld = lane_dev_made(L, dev))
+                if (ld->stream) (void)hipStreamSynchronize(ld->stream);
     }
-    for (size_t j = mine > 2 ? mine - 2 : 0; j < mine; j++) HIP_TRY(hipEventSynchronize(L.ev[j & 1]));
+    (void)hipGetLastError();
+}
+
+// ---- plain transfers over any number of devices ----------------------------------------------------------
+struct Chunk {
+    size_t seg, off, size;
+};
+// chunks of every segment, interleaved segment by segment so that every device's link is busy from the start
+std::vector<Chunk> interleave(const CopySeg* segs, size_t count, size_t chunk) {
+    std::vector<Chunk> out;
+    size_t most = 0;
+    for (size_t i = 0; i < count; i++) most = std::max(most, (segs[i].bytes + chunk - 1) / chunk);
+    for (size_t k = 0; k < most; k++)
+        for (size_t i = 0; i < count; i++)
+            if (k * chunk < segs[i].bytes) out.push_back(Chunk{i, k * chunk, std::min(chunk, segs[i].bytes - k * chunk)});
+    return out;
+}
+
+int lane_upload(Lane* L, int t, int T, const std::vector<Chunk>& chunks, const CopySeg* segs) {
+    hipEvent_t last[2] = {nullptr, nullptr};
+    int last_dev[2] = {-1, -1};
+    size_t j = 0;
+    for (size_t c = t; c < chunks.size(); c += T, j++) {
+        const int s = (int)(j & 1);
+        const Chunk& ch = chunks[c];
+        const CopySeg& seg = segs[ch.seg];
+        if (last[s]) {   // the DMA out of this buffer is through
+            HIP_TRY(hipSetDevice(last_dev[s]));
+            HIP_TRY(hipEventSynchronize(last[s]));
+        }
+        std::memcpy(L->pin[s], (const char*)seg.host + ch.off, ch.size);
+        HIP_TRY(hipSetDevice(seg.device));
+        LaneDev* ld = lane_dev_made(L, seg.device);
+        DeviceShared* ds = device_shared_made(seg.device);
+        {
+            std::lock_guard<std::mutex> issue(ds->issue);
+            HIP_TRY(hipMemcpyAsync((char*)seg.dev + ch.off, L->pin[s], ch.size, hipMemcpyHostToDevice, ds->up));
+            HIP_TRY(hipEventRecord(ld->ev[s], ds->up));
+        }
+        last[s] = ld->ev[s];
+        last_dev[s] = seg.device;
+    }
+    for (int s = 0; s < 2; s++)
+        if (last[s]) {
+            HIP_TRY(hipSetDevice(last_dev[s]));
+            HIP_TRY(hipEventSynchronize(last[s]));
+        }
     return FPGPU_OK;
 }
 
-int lane_download(DeviceLanes* d, int t, int T, char* host, const char* dev, size_t bytes) {
-    Lane& L = d->lanes[t];
-    HIP_TRY(hipStreamWaitEvent(L.stream, d->order, 0));
-    const size_t mine = lane_chunks((bytes + kDownChunk - 1) / kDownChunk, t, T);
+int lane_download(Lane* L, int t, int T, const std::vector<Chunk>& chunks, const CopySeg* segs) {
+    const size_t mine = chunks.size() > (size_t)t ? (chunks.size() - t + T - 1) / T : 0;
+    hipEvent_t evs[2] = {nullptr, nullptr};
+    int devs[2] = {-1, -1};
     auto issue = [&](size_t j) -> int {
         const int s = (int)(j & 1);
-        const size_t off = (t + j * T) * kDownChunk, sz = std::min(kDownChunk, bytes - off);
-        HIP_TRY(hipMemcpyAsync(g_stage.pin[t][s], dev + off, sz, hipMemcpyDeviceToHost, L.stream));
-        HIP_TRY(hipEventRecord(L.ev[s], L.stream));
+        const Chunk& ch = chunks[t + j * T];
+        const CopySeg& seg = segs[ch.seg];
+        HIP_TRY(hipSetDevice(seg.device));
+        LaneDev* ld = lane_dev_made(L, seg.device);
+        HIP_TRY(hipMemcpyAsync(L->pin[s], (const char*)seg.dev + ch.off, ch.size, hipMemcpyDeviceToHost, ld->stream));
+        HIP_TRY(hipEventRecord(ld->ev[s], ld->stream));
+        evs[s] = ld->ev[s];
+        devs[s] = seg.device;
         return FPGPU_OK;
     };
     if (mine) CHECK(issue(0));
     for (size_t j = 0; j < mine; j++) {
         const int s = (int)(j & 1);
         if (j + 1 < mine) CHECK(issue(j + 1));   // the other buffer: drained in the previous round
-        HIP_TRY(hipEventSynchronize(L.ev[s]));
-        const size_t off = (t + j * T) * kDownChunk, sz = std::min(kDownChunk, bytes - off);
-        std::memcpy(host + off, g_stage.pin[t][s], sz);
+        HIP_TRY(hipSetDevice(devs[s]));
+        HIP_TRY(hipEventSynchronize(evs[s]));
+        const Chunk& ch = chunks[t + j * T];
+        std::memcpy((char*)segs[ch.seg].host + ch.off, L->pin[s], ch.size);
     }
     return FPGPU_OK;
 }
 
-// Slot layout of the chunk pipeline (device and pinned alike), every region 256-byte aligned:
+int plain_multi(const CopySeg* segs, size_t count, bool up) {
+    for (size_t i = 0; i < count; i++) {
+        if (!segs[i].bytes) continue;
+        HIP_TRY(hipSetDevice(segs[i].device));
+        if (up) HIP_TRY(hipMemcpyAsync(segs[i].dev, segs[i].host, segs[i].bytes, hipMemcpyHostToDevice, segs[i].stream));
+        else HIP_TRY(hipMemcpyAsync(segs[i].host, segs[i].dev, segs[i].bytes, hipMemcpyDeviceToHost, segs[i].stream));
+    }
+    for (size_t i = 0; i < count; i++) {
+        if (!segs[i].bytes) continue;
+        HIP_TRY(hipSetDevice(segs[i].device));
+        HIP_TRY(hipStreamSynchronize(segs[i].stream));
+    }
+    return FPGPU_OK;
+}
+
+// Makes the lanes' and the devices' objects for every device of the transfer and orders the transfer behind
+// what each segment's stream holds so far.  FPGPU_ERR_UNSUPPORTED (nothing queued yet) when an object cannot
+// be made: the caller takes the plain path for this transfer.
+int prepare(const LaneSet& set, const CopySeg* segs, size_t count, bool up, std::vector<int>* devices) {
+    for (size_t i = 0; i < count; i++)
+        if (segs[i].bytes && std::find(devices->begin(), devices->end(), segs[i].device) == devices->end())
+            devices->push_back(segs[i].device);
+    for (int dev : *devices) {
+        DeviceShared* ds = nullptr;
+        if (hipSetDevice(dev) != hipSuccess || device_shared(dev, &ds) != FPGPU_OK) return FPGPU_ERR_UNSUPPORTED;
+        for (Lane* L : set.lanes) {
+            LaneDev* ld = nullptr;
+            if (lane_dev(L, dev, &ld) != FPGPU_OK) return FPGPU_ERR_UNSUPPORTED;
+        }
+    }
+    for (size_t i = 0; i < count; i++) {
+        if (!segs[i].bytes) continue;
+        HIP_TRY(hipSetDevice(segs[i].device));
+        LaneDev* l0 = lane_dev_made(set.lanes[0], segs[i].device);
+        HIP_TRY(hipEventRecord(l0->order, segs[i].stream));
+        if (up) {
+            HIP_TRY(hipStreamWaitEvent(device_shared_made(segs[i].device)->up, l0->order, 0));
+        } else {
+            for (Lane* L : set.lanes) HIP_TRY(hipStreamWaitEvent(lane_dev_made(L, segs[i].device)->stream, l0->order, 0));
+        }
+    }
+    return FPGPU_OK;
+}
+
+int staged_multi(const CopySeg* segs, size_t count, bool up) {
+    size_t total = 0;
+    std::vector<int> distinct;
+    for (size_t i = 0; i < count; i++) {
+        total += segs[i].bytes;
+        if (segs[i].bytes && std::find(distinct.begin(), distinct.end(), segs[i].device) == distinct.end())
+            distinct.push_back(segs[i].device);
+    }
+    if (total == 0) return FPGPU_OK;
+    DeviceGuard guard;
+    const int per = lanes_wanted();
+    if (total < kMinStaged || per == 1) return plain_multi(segs, count, up);
+    // every device has its own link to the host: a transfer that spans g devices may use g times the lanes
+    LaneSet set;
+    if (acquire_lanes((int)std::min<size_t>(kMaxLanes, (size_t)per * distinct.size()), &set) != FPGPU_OK)
+        return plain_multi(segs, count, up);
+    std::vector<int> devices;
+    const int prc = prepare(set, segs, count, up, &devices);
+    if (prc == FPGPU_ERR_UNSUPPORTED) {
+        (void)hipGetLastError();
+        return plain_multi(segs, count, up);
+    }
+    int rc = prc;
+    if (rc == FPGPU_OK) {
+        const std::vector<Chunk> chunks = interleave(segs, count, up ? kUpChunk : kDownChunk);
+        const int T = set.width();
+        rc = run_lanes(set, [&](int t) {
+            return up ? lane_upload(set.lanes[t], t, T, chunks, segs) : lane_download(set.lanes[t], t, T, chunks, segs);
+        });
+    }
+    if (rc != FPGPU_OK) {
+        const std::string msg = g_last_error;
+        drain(set, devices);
+        return fail(rc, msg);
+    }
+    return FPGPU_OK;
+}
+
+// ---- the chunk pipeline of the elementwise host calls ------------------------------------------------------
+// Slot layout (device and pinned alike), every region 256-byte aligned:
 //   a | b (if any) | out | flags (if any) | workspace (device only)
 struct SlotPlan {
     size_t per;                      // elements per chunk
@@ -281,21 +507,22 @@ SlotPlan plan_slot(const StreamJob& job, size_t per) {
     return p;
 }
 inline size_t slot_bytes(const SlotPlan& p) { return p.ws_off + up256(p.ws_bytes); }
+inline size_t lane_chunks(size_t chunks, int t, int T) { return chunks > (size_t)t ? (chunks - t + T - 1) / T : 0; }
 
 // chunk j of lane t: up (a | b in one DMA) on the upload stream; the kernels on the shared compute stream, or
 // on the lane's own when a chunk's kernels are latency-bound (several chunks then run side by side); down
 // (out | flags in one DMA) on the lane's own; two rounds later the lane copies the result out of the pinned
 // buffer and reuses the slot.
-int lane_map(DeviceLanes* d, int t, int T, const StreamJob& job, const SlotPlan& sp) {
-    Lane& L = d->lanes[t];
+int lane_map(Lane* L, LaneDev* ld, DeviceShared* d, int t, int T, const StreamJob& job, const SlotPlan& sp) {
+    HIP_TRY(hipSetDevice(d->device));
     const size_t esz = job.esz, per = sp.per, n = job.n;
     const size_t mine = lane_chunks((n + per - 1) / per, t, T);
     for (size_t j = 0; j < mine + 2; j++) {
         const int s = (int)(j & 1);
-        char* pin = g_stage.pin[t][s];
+        char* pin = L->pin[s];
         if (j >= 2) {
             const size_t first = (t + (j - 2) * T) * per, cnt = std::min(per, n - first);
-            HIP_TRY(hipEventSynchronize(L.ev[s]));
+            HIP_TRY(hipEventSynchronize(ld->ev[s]));
             std::memcpy((char*)job.out + first * esz, pin + sp.out_off, cnt * esz);
             if (job.flags) std::memcpy(job.flags + first, pin + sp.flags_off, cnt);
         }
@@ -303,21 +530,21 @@ int lane_map(DeviceLanes* d, int t, int T, const StreamJob& job, const SlotPlan&
             const size_t first = (t + j * T) * per, cnt = std::min(per, n - first), bytes = cnt * esz;
             std::memcpy(pin, (const char*)job.a + first * esz, bytes);
             if (job.b) std::memcpy(pin + sp.b_off, (const char*)job.b + first * esz, bytes);
-            char* dev = L.dev[s];
-            hipStream_t cs = job.lane_compute ? L.stream : d->compute;
+            char* dev = ld->dev[s];
+            hipStream_t cs = job.lane_compute ? ld->stream : d->compute;
             {
                 std::lock_guard<std::mutex> issue(d->issue);
                 HIP_TRY(hipMemcpyAsync(dev, pin, job.b ? sp.b_off + bytes : bytes, hipMemcpyHostToDevice, d->up));
-                HIP_TRY(hipEventRecord(L.uploaded[s], d->up));
-                HIP_TRY(hipStreamWaitEvent(cs, L.uploaded[s], 0));
+                HIP_TRY(hipEventRecord(ld->uploaded[s], d->up));
+                HIP_TRY(hipStreamWaitEvent(cs, ld->uploaded[s], 0));
                 CHECK(job.call(dev, job.b ? dev + sp.b_off : nullptr, dev + sp.out_off,
                                job.want_flags ? (uint8_t*)(dev + sp.flags_off) : nullptr, dev + sp.ws_off, sp.ws_bytes, cnt, cs));
-                if (!job.lane_compute) HIP_TRY(hipEventRecord(L.computed[s], d->compute));
+                if (!job.lane_compute) HIP_TRY(hipEventRecord(ld->computed[s], d->compute));
             }
-            if (!job.lane_compute) HIP_TRY(hipStreamWaitEvent(L.stream, L.computed[s], 0));
+            if (!job.lane_compute) HIP_TRY(hipStreamWaitEvent(ld->stream, ld->computed[s], 0));
             const size_t down = job.want_flags ? (sp.flags_off - sp.out_off) + cnt : bytes;   // out | flags in one DMA
-            HIP_TRY(hipMemcpyAsync(pin + sp.out_off, dev + sp.out_off, down, hipMemcpyDeviceToHost, L.stream));
-            HIP_TRY(hipEventRecord(L.ev[s], L.stream));
+            HIP_TRY(hipMemcpyAsync(pin + sp.out_off, dev + sp.out_off, down, hipMemcpyDeviceToHost, ld->stream));
+            HIP_TRY(hipEventRecord(ld->ev[s], ld->stream));
         }
     }
     return FPGPU_OK;
@@ -340,48 +567,25 @@ struct DevBuf {
 
 }  // namespace
 
-// The lanes need pinned host memory, streams and threads; where the process may not have them (a locked-
-// memory limit, no more streams) the transfers still work, through the runtime's own staging: the failure
-// is remembered and every later transfer takes the plain path.
-static bool g_lanes_unavailable = false;
-static DeviceLanes* lanes_or_null(int lanes, bool device_slots) {
-    if (g_lanes_unavailable) return nullptr;
-    DeviceLanes* d = nullptr;
-    if (acquire(lanes, &d) == FPGPU_OK && (!device_slots || ensure_device_slots(d, lanes) == FPGPU_OK)) return d;
-    (void)hipGetLastError();
-    g_lanes_unavailable = true;
-    return nullptr;
-}
-static int plain_copy(void* dst, const void* src, size_t bytes, hipMemcpyKind kind, hipStream_t stream) {
-    HIP_TRY(hipMemcpyAsync(dst, src, bytes, kind, stream));
-    HIP_TRY(hipStreamSynchronize(stream));
-    return FPGPU_OK;
-}
+// dev <- host (pageable) for every segment, each ordered after everything queued on its `stream`; returns when
+// the data is in device memory (later work on any stream sees it; the host ranges are the caller's again).
+// Segments on different devices are in flight together.
+int upload_staged_multi(const CopySeg* segs, size_t count) { return staged_multi(segs, count, true); }
+// host (pageable) <- dev for every segment, after everything queued on its `stream`; returns when the host
+// ranges hold the data.
+int download_staged_multi(const CopySeg* segs, size_t count) { return staged_multi(segs, count, false); }
 
-// dev <- host (pageable), ordered after everything queued on `stream` of the current device; returns when
-// the data is in device memory (so later work on any stream sees it and `host` is the caller's again).
 int upload_staged(void* dev, const void* host, size_t bytes, hipStream_t stream) {
     if (bytes == 0) return FPGPU_OK;
-    const int lanes = lanes_wanted();
-    if (bytes < kMinStaged || lanes == 1) return plain_copy(dev, host, bytes, hipMemcpyHostToDevice, stream);
-    std::lock_guard<std::mutex> lock(g_stage.mu);
-    DeviceLanes* d = lanes_or_null(lanes, false);
-    if (!d) return plain_copy(dev, host, bytes, hipMemcpyHostToDevice, stream);
-    HIP_TRY(hipEventRecord(d->order, stream));
-    HIP_TRY(hipStreamWaitEvent(d->up, d->order, 0));
-    return run_lanes(d, lanes, [&](int t) { return lane_upload(d, t, lanes, (char*)dev, (const char*)host, bytes); });
+    CopySeg seg{0, dev, const_cast<void*>(host), bytes, stream};
+    HIP_TRY(hipGetDevice(&seg.device));
+    return staged_multi(&seg, 1, true);
 }
-
-// host (pageable) <- dev, after everything queued on `stream`; returns when `host` holds the data.
 int download_staged(void* host, const void* dev, size_t bytes, hipStream_t stream) {
     if (bytes == 0) return FPGPU_OK;
-    const int lanes = lanes_wanted();
-    if (bytes < kMinStaged || lanes == 1) return plain_copy(host, dev, bytes, hipMemcpyDeviceToHost, stream);
-    std::lock_guard<std::mutex> lock(g_stage.mu);
-    DeviceLanes* d = lanes_or_null(lanes, false);
-    if (!d) return plain_copy(host, dev, bytes, hipMemcpyDeviceToHost, stream);
-    HIP_TRY(hipEventRecord(d->order, stream));
-    return run_lanes(d, lanes, [&](int t) { return lane_download(d, t, lanes, (char*)host, (const char*)dev, bytes); });
+    CopySeg seg{0, const_cast<void*>(dev), host, bytes, stream};
+    HIP_TRY(hipGetDevice(&seg.device));
+    return staged_multi(&seg, 1, false);
 }
 
 // out[i] = op(a[i], b[i]) for host arrays: `call(da, db, dout, count, stream)` queues the operation on
@@ -401,23 +605,54 @@ static int whole_operands_elementwise(const void* a, const void* b, void* out, s
 }
 
 // Whether a host-array call of this size takes the chunk pipeline (else: whole operands on the device).
-bool host_stream_usable(size_t bytes) { return bytes >= kMinStaged && lanes_wanted() > 1 && !g_lanes_unavailable; }
+bool host_stream_usable(size_t bytes) {
+    if (bytes < kMinStaged || lanes_wanted() <= 1) return false;
+    std::lock_guard<std::mutex> l(g_stage.mu);
+    return !g_stage.host_unavailable;
+}
 
 // The chunk pipeline for any per-element map of host arrays (see StreamJob): returns FPGPU_ERR_UNSUPPORTED
 // without touching anything when the lanes cannot be had -- the caller then takes its whole-operand path.
+// (A device that cannot hold a lane's slots -- out of memory -- only costs THIS call the pipeline.)
 int host_stream_map(const StreamJob& job) {
     if (job.n == 0) return FPGPU_OK;
-    const int lanes = lanes_wanted();
-    if (lanes == 1) return FPGPU_ERR_UNSUPPORTED;
-    std::lock_guard<std::mutex> lock(g_stage.mu);
-    DeviceLanes* d = lanes_or_null(lanes, true);
-    if (!d) return FPGPU_ERR_UNSUPPORTED;
+    const int want = lanes_wanted();
+    if (want == 1) return FPGPU_ERR_UNSUPPORTED;
     // the largest chunk (a multiple of 32 elements) whose slot fits
     size_t per = (kSlotBytes / (job.esz * (job.b ? 3 : 2) + 1)) & ~(size_t)31;
     while (per > 32 && slot_bytes(plan_slot(job, per)) > kSlotBytes) per -= std::max<size_t>(32, (per / 16) & ~(size_t)31);
     if (per < 32 || slot_bytes(plan_slot(job, per)) > kSlotBytes) return FPGPU_ERR_UNSUPPORTED;
     const SlotPlan sp = plan_slot(job, per);
-    return run_lanes(d, lanes, [&](int t) { return lane_map(d, t, lanes, job, sp); });
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    LaneSet set;
+    if (acquire_lanes(want, &set) != FPGPU_OK) return FPGPU_ERR_UNSUPPORTED;
+    DeviceShared* ds = nullptr;
+    std::vector<LaneDev*> lds;
+    bool ok = device_shared(dev, &ds) == FPGPU_OK;
+    for (Lane* L : set.lanes) {
+        LaneDev* ld = nullptr;
+        ok = ok && lane_dev(L, dev, &ld) == FPGPU_OK;
+        for (int s = 0; s < 2 && ok; s++)
+            if (!ld->dev[s] && hipMalloc((void**)&ld->dev[s], kSlotBytes) != hipSuccess) {
+                ld->dev[s] = nullptr;
+                ok = false;
+            }
+        lds.push_back(ld);
+    }
+    if (!ok) {
+        (void)hipGetLastError();
+        return FPGPU_ERR_UNSUPPORTED;
+    }
+    const int T = set.width();
+    const int rc = run_lanes(set, [&](int t) { return lane_map(set.lanes[t], lds[t], ds, t, T, job, sp); });
+    if (rc != FPGPU_OK) {
+        const std::string msg = g_last_error;
+        drain(set, std::vector<int>{dev});
+        (void)hipSetDevice(dev);
+        return fail(rc, msg);
+    }
+    return FPGPU_OK;
 }
 
 int host_stream_elementwise(const void* a, const void* b, void* out, size_t n, size_t esz, const ChunkCall& call) {

@@ -11,9 +11,19 @@
 // axis, rayon over `par_chunks_exact(num_cols)` (src/matrix.rs:170-184) -- with x / B replicated and
 // an all-gather of the output row blocks (RCCL over xGMI) when a replicated result is asked for.
 //
-// One host thread drives every device: each entry of the device list owns a stream, so the loops
+// One host thread drives every device of a call: each entry of a device list owns a stream, so the loops
 // below only enqueue work; nothing here blocks except upload / download / sync and the calls that
 // return a value to the host.
+//
+// Threads.  The reference's configs are Send + Sync and shared across rayon workers (src/lib.rs:62-65),
+// so any number of host threads may call in at once.  There is no library-wide lock on the call paths:
+//   g_reg_mu     the registry (slots, the default device list): held while a list or a vector is made;
+//   Slot::mu     held while ONE call enqueues the kernels that use the entry's scratch block (inversion,
+//                folds, matrix-core products), so two calls never interleave their use of it;
+//   g_coll_mu    the event-ordered peer copies and RCCL group calls of an all-gather / fpgpu_vec_copy:
+//                one such protocol at a time.
+// Elementwise operations take no lock at all.  Order: g_coll_mu before Slot::mu; g_reg_mu is never held
+// while another is taken.
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
@@ -32,7 +42,7 @@ using namespace fpgpu;
 
 namespace {
 
-// ---- one entry of the device list ------------------------------------------------------------
+// ---- one entry of a device list ------------------------------------------------------------
 struct Slot {
     int device = -1;
     hipStream_t stream = nullptr;
@@ -40,14 +50,44 @@ struct Slot {
     hipEvent_t done = nullptr;   // "I have finished reading my peers' parts"
     void* scratch = nullptr;     // grow-only workspace of the operations that need one
     size_t scratch_bytes = 0;
-    ncclComm_t comm = nullptr;   // this entry's communicator while g_comm_ready
+    std::mutex mu;               // see the header: one call at a time enqueues work that uses `scratch`
 };
 
-std::recursive_mutex g_mu;
+std::mutex g_reg_mu;
+std::mutex g_coll_mu;
 std::vector<std::unique_ptr<Slot>> g_slots;  // never destroyed: vectors keep pointers to their slots
-std::vector<Slot*> g_list;                   // fpgpu_set_devices; empty = not set (the current device)
-bool g_list_distinct = true;
-bool g_comm_ready = false;
+
+int rccl_destroy_comms(std::vector<ncclComm_t>& comms);
+
+// A device list: what fpgpu_set_devices installs as the default, or what fpgpu_devset_create returns.
+// Vectors hold a reference, so a list outlives fpgpu_set_devices / fpgpu_devset_destroy for as long as a
+// vector laid out over it exists.  The RCCL communicators of a list are made at its first all-gather.
+struct DevSet {
+    std::vector<Slot*> list;
+    bool distinct = true;
+    std::vector<ncclComm_t> comms;   // one per entry while comm_ready (guarded by g_coll_mu)
+    bool comm_ready = false;
+    ~DevSet() {
+        if (!comm_ready) return;
+        int prev = -1;
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        for (Slot* s : list)   // collectives still queued on an entry's stream must be through before its communicator goes
+            if (hipSetDevice(s->device) == hipSuccess) (void)hipStreamSynchronize(s->stream);
+        (void)rccl_destroy_comms(comms);
+        if (prev >= 0) (void)hipSetDevice(prev);
+        (void)hipGetLastError();
+    }
+};
+// the default list (fpgpu_set_devices); null = not set (the current device alone).  The holder itself is
+// never destroyed, so no communicator is torn down during static destruction at process exit.
+std::shared_ptr<DevSet>& default_set() {
+    static auto* holder = new std::shared_ptr<DevSet>();
+    return *holder;
+}
+std::vector<std::shared_ptr<DevSet>>& single_sets() {   // "the current device alone", one per device, made on demand
+    static auto* v = new std::vector<std::shared_ptr<DevSet>>();
+    return *v;
+}
 
 struct DeviceGuard {  // restores the caller's current device
     int prev = -1;
@@ -71,7 +111,7 @@ int device_count(int* n) {
     return FPGPU_OK;
 }
 
-int make_slot(int device, Slot** out) {
+int make_slot(int device, Slot** out) {   // g_reg_mu held
     auto s = std::make_unique<Slot>();
     s->device = device;
     HIP_TRY(hipSetDevice(device));
@@ -83,15 +123,16 @@ int make_slot(int device, Slot** out) {
     return FPGPU_OK;
 }
 
-// The slot that work placed on `device` uses: the first list entry on that device, else the first
-// slot ever made for it, else a new one.
-int slot_for_device(int device, Slot** out) {
-    for (Slot* s : g_list)
-        if (s->device == device) { *out = s; return FPGPU_OK; }
-    for (auto& s : g_slots)
-        if (s->device == device) { *out = s.get(); return FPGPU_OK; }
-    DeviceGuard guard;
-    return make_slot(device, out);
+// The k-th slot of `device` (made if there are fewer): the k-th mention of a device in any list takes the
+// device's k-th slot, so two lists that name a device share its stream and their work stays ordered.
+int nth_slot(int device, int k, Slot** out) {   // g_reg_mu held
+    int seen = 0;
+    for (auto& t : g_slots)
+        if (t->device == device && seen++ == k) { *out = t.get(); return FPGPU_OK; }
+    Slot* s = nullptr;
+    for (; seen <= k; seen++) CHECK(make_slot(device, &s));
+    *out = s;
+    return FPGPU_OK;
 }
 
 int current_device(int* dev) {
@@ -101,18 +142,56 @@ int current_device(int* dev) {
     return FPGPU_OK;
 }
 
-// The device list in effect: what fpgpu_set_devices set, else the current device alone.
-int effective_list(std::vector<Slot*>* out) {
-    if (!g_list.empty()) { *out = g_list; return FPGPU_OK; }
-    int dev = 0;
-    CHECK(current_device(&dev));
-    Slot* s = nullptr;
-    CHECK(slot_for_device(dev, &s));
-    out->assign(1, s);
+int build_set(const int* ids, int count, std::shared_ptr<DevSet>* out) {   // g_reg_mu held; ids validated
+    auto set = std::make_shared<DevSet>();
+    DeviceGuard guard;
+    for (int i = 0; i < count; i++) {
+        int k = 0;
+        for (int j = 0; j < i; j++) k += ids[j] == ids[i];
+        set->distinct = set->distinct && k == 0;
+        Slot* s = nullptr;
+        CHECK(nth_slot(ids[i], k, &s));
+        set->list.push_back(s);
+    }
+    // direct peer copies (fpgpu_vec_copy, the copy transport of the all-gather) between the list's devices:
+    // best effort -- without peer access hipMemcpyPeerAsync still works, staged by the runtime
+    for (Slot* a : set->list)
+        for (Slot* b : set->list) {
+            int can = 0;
+            if (a->device == b->device || hipSetDevice(a->device) != hipSuccess) continue;
+            if (hipDeviceCanAccessPeer(&can, a->device, b->device) == hipSuccess && can) (void)hipDeviceEnablePeerAccess(b->device, 0);
+            (void)hipGetLastError();   // "already enabled" included
+        }
+    *out = set;
     return FPGPU_OK;
 }
 
-int ensure_scratch(Slot* s, size_t bytes) {  // the slot's device must be current
+// The list a placement refers to: `given` (fpgpu_devset), else what fpgpu_set_devices set, else the
+// current device alone.
+int effective_set(const std::shared_ptr<DevSet>* given, std::shared_ptr<DevSet>* out) {   // g_reg_mu held
+    if (given && *given) { *out = *given; return FPGPU_OK; }
+    if (default_set()) { *out = default_set(); return FPGPU_OK; }
+    int dev = 0;
+    CHECK(current_device(&dev));
+    auto& singles = single_sets();
+    if ((int)singles.size() <= dev) singles.resize(dev + 1);
+    if (!singles[dev]) CHECK(build_set(&dev, 1, &singles[dev]));
+    *out = singles[dev];
+    return FPGPU_OK;
+}
+
+// The slot that work placed on ONE device uses: the first entry of the list in effect on that device, else
+// the device's first slot.
+int slot_for_device(const std::shared_ptr<DevSet>* given, int device, Slot** out) {   // g_reg_mu held
+    const std::shared_ptr<DevSet>& set = (given && *given) ? *given : default_set();
+    if (set)
+        for (Slot* s : set->list)
+            if (s->device == device) { *out = s; return FPGPU_OK; }
+    DeviceGuard guard;
+    return nth_slot(device, 0, out);
+}
+
+int ensure_scratch(Slot* s, size_t bytes) {  // the slot's device must be current, s->mu held
     if (bytes <= s->scratch_bytes) return FPGPU_OK;
     if (s->scratch) {
         HIP_TRY(hipStreamSynchronize(s->stream));  // earlier work may still be using the old block
@@ -170,27 +249,23 @@ int load_rccl() {
     return FPGPU_OK;
 }
 
-void destroy_comms() {
-    if (!g_comm_ready) return;
-    for (Slot* s : g_list)
-        if (s->comm) {
-            // collectives still queued on this entry's stream must be through before their communicator goes
-            if (hipSetDevice(s->device) == hipSuccess) (void)hipStreamSynchronize(s->stream);
-            (void)g_rccl.CommDestroy(s->comm);
-            s->comm = nullptr;
+int rccl_destroy_comms(std::vector<ncclComm_t>& comms) {
+    for (ncclComm_t& c : comms)
+        if (c && g_rccl.CommDestroy) {
+            (void)g_rccl.CommDestroy(c);
+            c = nullptr;
         }
-    g_comm_ready = false;
+    return FPGPU_OK;
 }
 
-int ensure_comms() {  // one communicator per list entry (ncclCommInitAll: one process, many devices)
-    if (g_comm_ready) return FPGPU_OK;
+int ensure_comms(DevSet* set) {  // g_coll_mu held; one communicator per list entry (ncclCommInitAll: one process, many devices)
+    if (set->comm_ready) return FPGPU_OK;
     CHECK(load_rccl());
     std::vector<int> devs;
-    for (Slot* s : g_list) devs.push_back(s->device);
-    std::vector<ncclComm_t> comms(devs.size());
-    RCCL_TRY(g_rccl.CommInitAll(comms.data(), (int)devs.size(), devs.data()));
-    for (size_t i = 0; i < g_list.size(); i++) g_list[i]->comm = comms[i];
-    g_comm_ready = true;
+    for (Slot* s : set->list) devs.push_back(s->device);
+    set->comms.assign(devs.size(), nullptr);
+    RCCL_TRY(g_rccl.CommInitAll(set->comms.data(), (int)devs.size(), devs.data()));
+    set->comm_ready = true;
     return FPGPU_OK;
 }
 
@@ -208,7 +283,12 @@ struct fpgpu_vec {
     size_t n = 0;
     int kind = VEC_SINGLE;
     std::vector<VecPart> parts;
+    std::shared_ptr<DevSet> set;   // the list a sharded / replicated vector is laid out over (null for VEC_SINGLE)
     size_t esz() const { return n64 ? (size_t)n64 * 8 : 4; }
+};
+// A device list as a handle (fpgpu_devset_create).
+struct fpgpu_devset {
+    std::shared_ptr<DevSet> set;
 };
 // Column indices of a SparseMatrix: the same container with 4-byte elements.
 struct fpgpu_idx {
@@ -224,44 +304,47 @@ int check_vec(const fpgpu_ctx* ctx, const fpgpu_vec* v, const char* name) {
     return FPGPU_OK;
 }
 
-int vec_alloc_n64(uint32_t n64, size_t n, size_t unit, int placement, fpgpu_vec** out);
-int vec_alloc(const fpgpu_ctx* ctx, size_t n, size_t unit, int placement, fpgpu_vec** out) {
+int vec_alloc_n64(const fpgpu_devset* on, uint32_t n64, size_t n, size_t unit, int placement, fpgpu_vec** out);
+int vec_alloc(const fpgpu_ctx* ctx, const fpgpu_devset* on, size_t n, size_t unit, int placement, fpgpu_vec** out) {
     if (!ctx || !out) return fail(FPGPU_ERR_SHAPE, "null pointer");
-    return vec_alloc_n64(ctx->n64, n, unit, placement, out);
+    return vec_alloc_n64(on, ctx->n64, n, unit, placement, out);
 }
-int vec_alloc_n64(uint32_t n64, size_t n, size_t unit, int placement, fpgpu_vec** out) {
+int vec_alloc_n64(const fpgpu_devset* on, uint32_t n64, size_t n, size_t unit, int placement, fpgpu_vec** out) {
     if (!out) return fail(FPGPU_ERR_SHAPE, "null pointer");
     *out = nullptr;
     if (n > ((size_t)1 << 40)) return fail(FPGPU_ERR_SHAPE, "element count too large");
     if (unit == 0) unit = 1;
     if (n % unit) return fail(FPGPU_ERR_SHAPE, "vec_alloc: length is not a whole number of rows");
-    std::lock_guard<std::recursive_mutex> lock(g_mu);
     int ndev = 0;
     CHECK(device_count(&ndev));
     DeviceGuard guard;
     auto v = std::make_unique<fpgpu_vec>();
     v->n64 = n64;
     v->n = n;
-    if (placement >= 0 || placement == FPGPU_PLACE_CURRENT) {
-        int dev = placement;
-        if (placement == FPGPU_PLACE_CURRENT) CHECK(current_device(&dev));
-        if (dev >= ndev) return fail(FPGPU_ERR_SHAPE, "vec_alloc: no such device");
-        Slot* s = nullptr;
-        CHECK(slot_for_device(dev, &s));
-        v->kind = VEC_SINGLE;
-        v->parts.push_back(VecPart{s, 0, n, nullptr});
-    } else if (placement == FPGPU_PLACE_SHARDED || placement == FPGPU_PLACE_REPLICATED) {
-        std::vector<Slot*> list;
-        CHECK(effective_list(&list));
-        const size_t g = list.size(), units = n / unit, base = units / g, rem = units % g;
-        v->kind = placement == FPGPU_PLACE_SHARDED ? VEC_SHARDED : VEC_REPLICATED;
-        for (size_t i = 0; i < g; i++) {
-            if (v->kind == VEC_REPLICATED) v->parts.push_back(VecPart{list[i], 0, n, nullptr});
-            else  // contiguous, balanced: the first `rem` devices take one unit more
-                v->parts.push_back(VecPart{list[i], (i * base + std::min(i, rem)) * unit, (base + (i < rem ? 1 : 0)) * unit, nullptr});
+    {
+        std::lock_guard<std::mutex> lock(g_reg_mu);
+        const std::shared_ptr<DevSet>* given = on ? &on->set : nullptr;
+        if (placement >= 0 || placement == FPGPU_PLACE_CURRENT) {
+            int dev = placement;
+            if (placement == FPGPU_PLACE_CURRENT) CHECK(current_device(&dev));
+            if (dev >= ndev) return fail(FPGPU_ERR_SHAPE, "vec_alloc: no such device");
+            Slot* s = nullptr;
+            CHECK(slot_for_device(given, dev, &s));
+            v->kind = VEC_SINGLE;
+            v->parts.push_back(VecPart{s, 0, n, nullptr});
+        } else if (placement == FPGPU_PLACE_SHARDED || placement == FPGPU_PLACE_REPLICATED) {
+            CHECK(effective_set(given, &v->set));
+            const std::vector<Slot*>& list = v->set->list;
+            const size_t g = list.size(), units = n / unit, base = units / g, rem = units % g;
+            v->kind = placement == FPGPU_PLACE_SHARDED ? VEC_SHARDED : VEC_REPLICATED;
+            for (size_t i = 0; i < g; i++) {
+                if (v->kind == VEC_REPLICATED) v->parts.push_back(VecPart{list[i], 0, n, nullptr});
+                else  // contiguous, balanced: the first `rem` devices take one unit more
+                    v->parts.push_back(VecPart{list[i], (i * base + std::min(i, rem)) * unit, (base + (i < rem ? 1 : 0)) * unit, nullptr});
+            }
+        } else {
+            return fail(FPGPU_ERR_SHAPE, "vec_alloc: unknown placement");
         }
-    } else {
-        return fail(FPGPU_ERR_SHAPE, "vec_alloc: unknown placement");
     }
     for (VecPart& p : v->parts) {
         hipError_t e = hipSetDevice(p.slot->device);
@@ -310,7 +393,6 @@ int vec_binary(BinaryDev fn, const fpgpu_ctx* ctx, const fpgpu_vec* a, const fpg
     CHECK(check_vec(ctx, a, "a"));
     CHECK(check_vec(ctx, b, "b"));
     CHECK(check_vec(ctx, out, "out"));
-    std::lock_guard<std::recursive_mutex> lock(g_mu);
     DeviceGuard guard;
     for (size_t pi = 0; pi < out->parts.size(); pi++) {
         const VecPart& o = out->parts[pi];
@@ -325,7 +407,6 @@ int vec_binary(BinaryDev fn, const fpgpu_ctx* ctx, const fpgpu_vec* a, const fpg
 int vec_unary(UnaryDev fn, const fpgpu_ctx* ctx, const fpgpu_vec* a, fpgpu_vec* out) {
     CHECK(check_vec(ctx, a, "a"));
     CHECK(check_vec(ctx, out, "out"));
-    std::lock_guard<std::recursive_mutex> lock(g_mu);
     DeviceGuard guard;
     for (size_t pi = 0; pi < out->parts.size(); pi++) {
         const VecPart& o = out->parts[pi];
@@ -379,7 +460,8 @@ int allgather_copy(fpgpu_vec* y, const std::vector<Range>& r) {
 }
 
 int allgather_rccl(fpgpu_vec* y, const std::vector<Range>& r) {
-    CHECK(ensure_comms());
+    CHECK(ensure_comms(y->set.get()));
+    const std::vector<ncclComm_t>& comms = y->set->comms;
     const size_t g = y->parts.size(), esz = y->esz(), w = y->n64;
     bool equal = true;
     for (size_t i = 0; i < g; i++) equal = equal && r[i].count == r[0].count && r[i].first == i * r[0].count;
@@ -389,12 +471,12 @@ int allgather_rccl(fpgpu_vec* y, const std::vector<Range>& r) {
         char* base = y->parts[i].ptr;
         if (equal) {
             if (r[0].count)
-                RCCL_TRY(g_rccl.AllGather(base + r[i].first * esz, base, r[0].count * w, ncclUint64, si->comm, si->stream));
+                RCCL_TRY(g_rccl.AllGather(base + r[i].first * esz, base, r[0].count * w, ncclUint64, comms[i], si->stream));
         } else {
             for (size_t root = 0; root < g; root++)
                 if (r[root].count)
                     RCCL_TRY(g_rccl.Broadcast(base + r[root].first * esz, base + r[root].first * esz, r[root].count * w,
-                                              ncclUint64, (int)root, si->comm, si->stream));
+                                              ncclUint64, (int)root, comms[i], si->stream));
         }
     }
     RCCL_TRY(g_rccl.GroupEnd());
@@ -402,14 +484,11 @@ int allgather_rccl(fpgpu_vec* y, const std::vector<Range>& r) {
 }
 
 int allgather(fpgpu_vec* y, const std::vector<Range>& r) {
-    // no device list set: one copy on the current device, which already holds everything
-    if (g_list.empty() && y->kind == VEC_REPLICATED && y->parts.size() == 1) return FPGPU_OK;
-    // y must be replicated over exactly the current device list, in order
-    if (y->kind != VEC_REPLICATED || g_list.empty() || y->parts.size() != g_list.size())
-        return fail(FPGPU_ERR_SHAPE, "all-gather: the output is not replicated over the current device list");
-    for (size_t i = 0; i < g_list.size(); i++)
-        if (y->parts[i].slot != g_list[i]) return fail(FPGPU_ERR_SHAPE, "all-gather: the output was allocated under another device list");
-    if (!g_list_distinct || tuning().allgather_copy > 0) return allgather_copy(y, r);
+    if (y->kind != VEC_REPLICATED || !y->set || y->parts.size() != y->set->list.size() || r.size() != y->parts.size())
+        return fail(FPGPU_ERR_SHAPE, "all-gather: the output is not replicated over a device list");
+    if (y->parts.size() == 1) return FPGPU_OK;   // one copy, which already holds everything
+    std::lock_guard<std::mutex> lock(g_coll_mu);
+    if (!y->set->distinct || tuning().allgather_copy > 0) return allgather_copy(y, r);
     return allgather_rccl(y, r);
 }
 
@@ -424,7 +503,9 @@ int rowblock_product(const fpgpu_vec* A, size_t rows, size_t row_len, fpgpu_vec*
     const bool gather = out->kind == VEC_REPLICATED && A->kind != VEC_REPLICATED;
     if (!gather && out->parts.size() != A->parts.size())
         return fail(FPGPU_ERR_SHAPE, std::string(what) + ": output is partitioned differently from A's rows");
-    std::vector<Range> ranges;
+    // what every copy of a gathered output contributes: one range per OUTPUT part, empty for a copy whose
+    // device holds no rows of A (A on fewer devices than the output's list)
+    std::vector<Range> ranges(out->parts.size(), Range{0, 0});
     DeviceGuard guard;
     for (size_t pi = 0; pi < A->parts.size(); pi++) {
         const VecPart& a = A->parts[pi];
@@ -439,17 +520,21 @@ int rowblock_product(const fpgpu_vec* A, size_t rows, size_t row_len, fpgpu_vec*
         }
         char* dst = nullptr;
         if (gather) {
-            if (pi >= out->parts.size() || out->parts[pi].slot != a.slot)
+            size_t oi = out->parts.size();
+            for (size_t j = 0; j < out->parts.size(); j++)
+                if (out->parts[j].slot == a.slot) { oi = j; break; }
+            if (oi == out->parts.size())
                 return fail(FPGPU_ERR_SHAPE, std::string(what) + ": replicated output has no copy on a device that holds rows of A");
-            dst = out->parts[pi].ptr + prow0 * out_len * out->esz();
+            dst = out->parts[oi].ptr + prow0 * out_len * out->esz();
+            ranges[oi] = Range{prow0 * out_len, prows * out_len};
         } else {
             const VecPart& o = out->parts[pi];
             if (o.slot != a.slot || o.first != prow0 * out_len || o.count != prows * out_len)
                 return fail(FPGPU_ERR_SHAPE, std::string(what) + ": output is partitioned differently from A's rows");
             dst = o.ptr;
         }
-        ranges.push_back(Range{prow0 * out_len, prows * out_len});
         HIP_TRY(hipSetDevice(a.slot->device));
+        std::lock_guard<std::mutex> lock(a.slot->mu);   // the body may use the entry's scratch block
         CHECK(body(pi, prows, prow0, dst));
     }
     if (gather) CHECK(allgather(out, ranges));
@@ -460,7 +545,6 @@ int rowblock_product(const fpgpu_vec* A, size_t rows, size_t row_len, fpgpu_vec*
 template <typename PartCall>
 int vec_reduce(const fpgpu_ctx* ctx, const fpgpu_vec* v, bool product, uint64_t* out_host, PartCall&& call) {
     if (!out_host) return fail(FPGPU_ERR_SHAPE, "null host pointer: out");
-    std::lock_guard<std::recursive_mutex> lock(g_mu);
     DeviceGuard guard;
     const size_t esz = v->esz(), fold_ws = fpgpu_fold_workspace_bytes(ctx);
     const size_t nparts = v->kind == VEC_REPLICATED ? 1 : v->parts.size();  // a replica holds everything
@@ -468,6 +552,8 @@ int vec_reduce(const fpgpu_ctx* ctx, const fpgpu_vec* v, bool product, uint64_t*
     for (size_t pi = 0; pi < nparts; pi++) {
         const VecPart& p = v->parts[pi];
         HIP_TRY(hipSetDevice(p.slot->device));
+        // the result leaves the scratch block in stream order (the copy below), so the lock ends with the enqueue
+        std::lock_guard<std::mutex> lock(p.slot->mu);
         CHECK(ensure_scratch(p.slot, fold_ws + 256));
         char* res = (char*)p.slot->scratch + fold_ws;
         CHECK(call(pi, p, res, p.slot->scratch, fold_ws));
@@ -484,6 +570,7 @@ int vec_reduce(const fpgpu_ctx* ctx, const fpgpu_vec* v, bool product, uint64_t*
     // fold the per-device partials on the first device (g elements: one small launch)
     Slot* s = v->parts[0].slot;
     HIP_TRY(hipSetDevice(s->device));
+    std::lock_guard<std::mutex> lock(s->mu);
     CHECK(ensure_scratch(s, fold_ws + 256 + nparts * esz));
     char* res = (char*)s->scratch + fold_ws;
     char* in = res + 256;
@@ -499,62 +586,81 @@ int vec_reduce(const fpgpu_ctx* ctx, const fpgpu_vec* v, bool product, uint64_t*
 
 extern "C" {
 
-// ---- device list --------------------------------------------------------------------------------
-int fpgpu_set_devices(const int* ids, int count) {
-    std::lock_guard<std::recursive_mutex> lock(g_mu);
-    if (count < 0 || count > 64 || (count > 0 && !ids)) return fail(FPGPU_ERR_SHAPE, "set_devices: bad device list");
+// ---- device lists --------------------------------------------------------------------------------
+static int check_ids(const int* ids, int count, const char* who) {
+    if (count < 0 || count > 64 || (count > 0 && !ids)) return fail(FPGPU_ERR_SHAPE, std::string(who) + ": bad device list");
     int ndev = 0;
     if (count > 0) CHECK(device_count(&ndev));
     for (int i = 0; i < count; i++)
-        if (ids[i] < 0 || ids[i] >= ndev) return fail(FPGPU_ERR_SHAPE, "set_devices: no such device");
-    DeviceGuard guard;
-    destroy_comms();
-    std::vector<Slot*> list;
-    bool distinct = true;
-    for (int i = 0; i < count; i++) {
-        // the k-th mention of a device takes that device's k-th slot (a new one if there is none yet)
-        int k = 0;
-        for (int j = 0; j < i; j++) k += ids[j] == ids[i];
-        distinct = distinct && k == 0;
-        Slot* s = nullptr;
-        int seen = 0;
-        for (auto& t : g_slots)
-            if (t->device == ids[i] && seen++ == k) { s = t.get(); break; }
-        if (!s) CHECK(make_slot(ids[i], &s));
-        list.push_back(s);
+        if (ids[i] < 0 || ids[i] >= ndev) return fail(FPGPU_ERR_SHAPE, std::string(who) + ": no such device");
+    return FPGPU_OK;
+}
+
+int fpgpu_set_devices(const int* ids, int count) {
+    CHECK(check_ids(ids, count, "set_devices"));
+    std::shared_ptr<DevSet> fresh, old;
+    {
+        std::lock_guard<std::mutex> lock(g_reg_mu);
+        if (count > 0) CHECK(build_set(ids, count, &fresh));
+        old = default_set();
+        default_set() = fresh;
     }
-    g_list = list;
-    g_list_distinct = distinct;
-    // direct peer copies (fpgpu_vec_copy, the copy transport of the all-gather) between the list's devices:
-    // best effort -- without peer access hipMemcpyPeerAsync still works, staged by the runtime
-    for (Slot* a : g_list)
-        for (Slot* b : g_list) {
-            int can = 0;
-            if (a->device == b->device || hipSetDevice(a->device) != hipSuccess) continue;
-            if (hipDeviceCanAccessPeer(&can, a->device, b->device) == hipSuccess && can) (void)hipDeviceEnablePeerAccess(b->device, 0);
-            (void)hipGetLastError();   // "already enabled" included
-        }
+    // `old` goes here, outside the registry lock (its communicators, unless a vector still holds the list)
+    std::lock_guard<std::mutex> coll(g_coll_mu);
+    old.reset();
     return FPGPU_OK;
 }
 
 int fpgpu_get_devices(int* ids, int capacity) {
-    std::lock_guard<std::recursive_mutex> lock(g_mu);
-    for (int i = 0; i < (int)g_list.size() && i < capacity && ids; i++) ids[i] = g_list[i]->device;
-    return (int)g_list.size();
+    std::lock_guard<std::mutex> lock(g_reg_mu);
+    const std::shared_ptr<DevSet>& set = default_set();
+    if (!set) return 0;
+    for (int i = 0; i < (int)set->list.size() && i < capacity && ids; i++) ids[i] = set->list[i]->device;
+    return (int)set->list.size();
+}
+
+int fpgpu_devset_create(const int* ids, int count, fpgpu_devset** out) {
+    if (!out) return fail(FPGPU_ERR_SHAPE, "null pointer");
+    *out = nullptr;
+    if (count <= 0) return fail(FPGPU_ERR_SHAPE, "devset_create: empty device list");
+    CHECK(check_ids(ids, count, "devset_create"));
+    auto h = std::unique_ptr<fpgpu_devset>(new (std::nothrow) fpgpu_devset());
+    if (!h) return fail(FPGPU_ERR_HIP, "out of host memory");
+    std::lock_guard<std::mutex> lock(g_reg_mu);
+    CHECK(build_set(ids, count, &h->set));
+    *out = h.release();
+    return FPGPU_OK;
+}
+void fpgpu_devset_destroy(fpgpu_devset* set) {
+    if (!set) return;
+    std::lock_guard<std::mutex> coll(g_coll_mu);   // the last reference tears the communicators down
+    delete set;
+}
+int fpgpu_devset_devices(const fpgpu_devset* set, int* ids, int capacity) {
+    if (!set || !set->set) return 0;
+    for (int i = 0; i < (int)set->set->list.size() && i < capacity && ids; i++) ids[i] = set->set->list[i]->device;
+    return (int)set->set->list.size();
 }
 
 // ---- vectors ----------------------------------------------------------------------------------------
 int fpgpu_vec_alloc(const fpgpu_ctx* ctx, size_t n, int placement, fpgpu_vec** out) {
-    return vec_alloc(ctx, n, 1, placement, out);
+    return vec_alloc(ctx, nullptr, n, 1, placement, out);
 }
 int fpgpu_vec_alloc_rows(const fpgpu_ctx* ctx, size_t rows, size_t cols, int placement, fpgpu_vec** out) {
     if (cols && rows > ((size_t)1 << 40) / cols) return fail(FPGPU_ERR_SHAPE, "matrix too large");
-    return vec_alloc(ctx, rows * cols, cols, placement, out);
+    return vec_alloc(ctx, nullptr, rows * cols, cols, placement, out);
+}
+int fpgpu_vec_alloc_on(const fpgpu_ctx* ctx, const fpgpu_devset* set, size_t n, int placement, fpgpu_vec** out) {
+    return vec_alloc(ctx, set, n, 1, placement, out);
+}
+int fpgpu_vec_alloc_rows_on(const fpgpu_ctx* ctx, const fpgpu_devset* set, size_t rows, size_t cols, int placement,
+                            fpgpu_vec** out) {
+    if (cols && rows > ((size_t)1 << 40) / cols) return fail(FPGPU_ERR_SHAPE, "matrix too large");
+    return vec_alloc(ctx, set, rows * cols, cols, placement, out);
 }
 
 void fpgpu_vec_free(fpgpu_vec* v) {
     if (!v) return;
-    std::lock_guard<std::recursive_mutex> lock(g_mu);
     DeviceGuard guard;
     for (VecPart& p : v->parts)
         if (p.ptr) {
@@ -562,6 +668,7 @@ void fpgpu_vec_free(fpgpu_vec* v) {
             (void)hipStreamSynchronize(p.slot->stream);
             (void)hipFree(p.ptr);
         }
+    std::lock_guard<std::mutex> coll(g_coll_mu);   // the last reference to a list tears its communicators down
     delete v;
 }
 
@@ -588,18 +695,17 @@ static int vec_upload_bytes(fpgpu_vec* v, const char* host, size_t first, size_t
     if (first > v->n || n > v->n - first) return fail(FPGPU_ERR_SHAPE, "vec_upload: range beyond the vector");
     if (n == 0) return FPGPU_OK;
     if (!host) return fail(FPGPU_ERR_SHAPE, "null host pointer");
-    std::lock_guard<std::recursive_mutex> lock(g_mu);
-    DeviceGuard guard;
     const size_t esz = v->esz();
-    for (VecPart& p : v->parts) {  // every part that overlaps the range (every copy of a replicated vector)
+    // every part that overlaps the range (every copy of a replicated vector), all devices in flight together:
+    // each part's copies are ordered behind what its stream holds, and the data is in device memory on return
+    std::vector<CopySeg> segs;
+    for (VecPart& p : v->parts) {
         const size_t lo = std::max(first, p.first), hi = std::min(first + n, p.first + p.count);
         if (lo >= hi) continue;
-        HIP_TRY(hipSetDevice(p.slot->device));
-        // (returns when the host range has been read; the last chunks may still be in flight on the
-        // part's stream, which orders every later operation on this vector behind them)
-        CHECK(upload_staged(p.ptr + (lo - p.first) * esz, host + (lo - first) * esz, (hi - lo) * esz, p.slot->stream));
+        segs.push_back(CopySeg{p.slot->device, p.ptr + (lo - p.first) * esz, const_cast<char*>(host) + (lo - first) * esz,
+                               (hi - lo) * esz, p.slot->stream});
     }
-    return FPGPU_OK;
+    return upload_staged_multi(segs.data(), segs.size());
 }
 
 static int vec_download_bytes(const fpgpu_vec* v, char* host, size_t first, size_t n);
@@ -612,22 +718,20 @@ static int vec_download_bytes(const fpgpu_vec* v, char* host, size_t first, size
     if (first > v->n || n > v->n - first) return fail(FPGPU_ERR_SHAPE, "vec_download: range beyond the vector");
     if (n == 0) return FPGPU_OK;
     if (!host) return fail(FPGPU_ERR_SHAPE, "null host pointer");
-    std::lock_guard<std::recursive_mutex> lock(g_mu);
-    DeviceGuard guard;
     const size_t esz = v->esz(), nparts = v->kind == VEC_REPLICATED ? 1 : v->parts.size();
+    std::vector<CopySeg> segs;
     for (size_t pi = 0; pi < nparts; pi++) {
         const VecPart& p = v->parts[pi];
         const size_t lo = std::max(first, p.first), hi = std::min(first + n, p.first + p.count);
         if (lo >= hi) continue;
-        HIP_TRY(hipSetDevice(p.slot->device));
-        CHECK(download_staged(host + (lo - first) * esz, p.ptr + (lo - p.first) * esz, (hi - lo) * esz, p.slot->stream));
+        segs.push_back(CopySeg{p.slot->device, p.ptr + (lo - p.first) * esz, host + (lo - first) * esz, (hi - lo) * esz,
+                               p.slot->stream});
     }
-    return FPGPU_OK;
+    return download_staged_multi(segs.data(), segs.size());
 }
 
 int fpgpu_vec_sync(const fpgpu_vec* v) {
     if (!v) return fail(FPGPU_ERR_SHAPE, "null vector");
-    std::lock_guard<std::recursive_mutex> lock(g_mu);
     DeviceGuard guard;
     for (const VecPart& p : v->parts) {
         HIP_TRY(hipSetDevice(p.slot->device));
@@ -642,7 +746,7 @@ int fpgpu_vec_copy(fpgpu_vec* dst, const fpgpu_vec* src) {
     if (!dst || !src) return fail(FPGPU_ERR_SHAPE, "null vector");
     if (dst->n != src->n || dst->n64 != src->n64) return fail(FPGPU_ERR_SHAPE, "vec_copy: length or element width mismatch");
     if (dst == src) return FPGPU_OK;
-    std::lock_guard<std::recursive_mutex> lock(g_mu);
+    std::lock_guard<std::mutex> lock(g_coll_mu);   // an event-ordered protocol over the entries' shared events
     DeviceGuard guard;
     const size_t esz = dst->esz();
     std::vector<Slot*> srcs, dsts;
@@ -685,7 +789,6 @@ int fpgpu_vec_copy(fpgpu_vec* dst, const fpgpu_vec* src) {
 
 int fpgpu_vec_fill_random(const fpgpu_ctx* ctx, fpgpu_vec* v, uint64_t seed) {
     CHECK(check_vec(ctx, v, "v"));
-    std::lock_guard<std::recursive_mutex> lock(g_mu);
     DeviceGuard guard;
     for (VecPart& p : v->parts) {
         if (p.count == 0) continue;
@@ -721,7 +824,6 @@ int fpgpu_vec_mul_chain(const fpgpu_ctx* ctx, const fpgpu_vec* a, const fpgpu_ve
     CHECK(check_vec(ctx, a, "a"));
     CHECK(check_vec(ctx, b, "b"));
     CHECK(check_vec(ctx, out, "out"));
-    std::lock_guard<std::recursive_mutex> lock(g_mu);
     DeviceGuard guard;
     for (size_t pi = 0; pi < out->parts.size(); pi++) {
         const VecPart& o = out->parts[pi];
@@ -738,7 +840,6 @@ int fpgpu_vec_pow(const fpgpu_ctx* ctx, const fpgpu_vec* a, const uint64_t* expo
                   fpgpu_vec* out) {
     CHECK(check_vec(ctx, a, "a"));
     CHECK(check_vec(ctx, out, "out"));
-    std::lock_guard<std::recursive_mutex> lock(g_mu);
     DeviceGuard guard;
     for (size_t pi = 0; pi < out->parts.size(); pi++) {
         const VecPart& o = out->parts[pi];
@@ -769,7 +870,6 @@ static int vec_inv_or_div(const fpgpu_ctx* ctx, const fpgpu_vec* a, const fpgpu_
     CHECK(check_vec(ctx, x, "x"));
     CHECK(check_vec(ctx, out, "out"));
     if (x == out) return fail(FPGPU_ERR_SHAPE, "batch_inv: out must not alias x");
-    std::lock_guard<std::recursive_mutex> lock(g_mu);
     DeviceGuard guard;
     const bool want_flags = none_flags_host || none_count;
     std::vector<uint8_t> tmp;
@@ -786,6 +886,7 @@ static int vec_inv_or_div(const fpgpu_ctx* ctx, const fpgpu_vec* a, const fpgpu_
         if (o.count == 0) continue;
         HIP_TRY(hipSetDevice(o.slot->device));
         const size_t wsb = (fpgpu_batch_inv_workspace_bytes(ctx, o.count) + 255) & ~(size_t)255;
+        std::lock_guard<std::mutex> lock(o.slot->mu);   // workspace and flags live in the entry's scratch block
         CHECK(ensure_scratch(o.slot, wsb + o.count));
         uint8_t* dflags = (uint8_t*)o.slot->scratch + wsb;
         CHECK(fpgpu_batch_inv_dev(ctx, px, o.ptr, dflags, o.count, o.slot->scratch, wsb, o.slot->stream));
@@ -838,7 +939,6 @@ int fpgpu_vec_matvec(const fpgpu_ctx* ctx, const fpgpu_vec* A, size_t rows, size
     CHECK(check_vec(ctx, x, "x"));
     CHECK(check_vec(ctx, y, "y"));
     if (x->n != cols) return fail(FPGPU_ERR_SHAPE, "matvec: x does not hold cols elements");
-    std::lock_guard<std::recursive_mutex> lock(g_mu);
     return rowblock_product(A, rows, cols, y, 1, "matvec", [&](size_t pi, size_t prows, size_t, char* dst) {
         const VecPart& a = A->parts[pi];
         if (prows == 0) return (int)FPGPU_OK;
@@ -856,7 +956,6 @@ int fpgpu_vec_matmul(const fpgpu_ctx* ctx, const fpgpu_vec* A, const fpgpu_vec* 
     CHECK(check_vec(ctx, B, "B"));
     CHECK(check_vec(ctx, C, "C"));
     if (B->n != k * n) return fail(FPGPU_ERR_SHAPE, "matmul: B does not hold k x n elements");
-    std::lock_guard<std::recursive_mutex> lock(g_mu);
     return rowblock_product(A, m, k, C, n, "matmul", [&](size_t pi, size_t prows, size_t, char* dst) {
         const VecPart& a = A->parts[pi];
         if (prows == 0) return (int)FPGPU_OK;
@@ -871,12 +970,16 @@ int fpgpu_vec_matmul(const fpgpu_ctx* ctx, const fpgpu_vec* A, const fpgpu_vec* 
 // ---- sparse mat-vec over SparseMatrix<T> (src/matrix.rs:46-61) on handles ------------------------------
 // The cells' two halves live in two containers with the same row partition: `vals` (rows * density
 // elements, fpgpu_vec_alloc_rows(rows, density)) and `col_idx` (rows * density 32-bit column indices).
+int fpgpu_idx_alloc_rows_on(const fpgpu_devset* on, size_t rows, size_t density, int placement, fpgpu_idx** out);
 int fpgpu_idx_alloc_rows(size_t rows, size_t density, int placement, fpgpu_idx** out) {
+    return fpgpu_idx_alloc_rows_on(nullptr, rows, density, placement, out);
+}
+int fpgpu_idx_alloc_rows_on(const fpgpu_devset* on, size_t rows, size_t density, int placement, fpgpu_idx** out) {
     if (!out) return fail(FPGPU_ERR_SHAPE, "null pointer");
     *out = nullptr;
     if (density && rows > ((size_t)1 << 40) / density) return fail(FPGPU_ERR_SHAPE, "sparse matrix too large");
     fpgpu_vec* v = nullptr;
-    CHECK(vec_alloc_n64(0, rows * density, density, placement, &v));
+    CHECK(vec_alloc_n64(on, 0, rows * density, density, placement, &v));
     auto idx = new (std::nothrow) fpgpu_idx();
     if (!idx) {
         fpgpu_vec_free(v);
@@ -906,7 +1009,6 @@ int fpgpu_vec_spmv(const fpgpu_ctx* ctx, const fpgpu_vec* vals, const fpgpu_idx*
     if (!col_idx) return fail(FPGPU_ERR_SHAPE, "null index vector");
     if (x->n != cols) return fail(FPGPU_ERR_SHAPE, "spmv: x does not hold cols elements");
     if (col_idx->v.n != vals->n) return fail(FPGPU_ERR_SHAPE, "spmv: values and column indices differ in length");
-    std::lock_guard<std::recursive_mutex> lock(g_mu);
     return rowblock_product(vals, rows, density, y, 1, "spmv", [&](size_t pi, size_t prows, size_t, char* dst) {
         const VecPart& a = vals->parts[pi];
         if (prows == 0) return (int)FPGPU_OK;

@@ -225,13 +225,28 @@ struct SparseMatrix {
 enum class Placement : int { Current = FPGPU_PLACE_CURRENT, Sharded = FPGPU_PLACE_SHARDED, Replicated = FPGPU_PLACE_REPLICATED };
 inline void set_devices(const std::vector<int>& ids) { fpgpu_check(fpgpu_set_devices(ids.data(), (int)ids.size())); }
 
+// A device list as a value (fpgpu_devset): vectors made with it do not depend on the process-wide list.
+class DeviceSet {
+   public:
+    explicit DeviceSet(const std::vector<int>& ids) {
+        fpgpu_devset* raw = nullptr;
+        fpgpu_check(fpgpu_devset_create(ids.data(), (int)ids.size(), &raw));
+        h_.reset(raw, [](fpgpu_devset* s) { fpgpu_devset_destroy(s); });
+    }
+    const fpgpu_devset* raw() const { return h_.get(); }
+
+   private:
+    std::shared_ptr<fpgpu_devset> h_;
+};
+
 class DeviceVec {
    public:
     DeviceVec() = default;
-    DeviceVec(const fpgpu_ctx* ctx, size_t n, Placement where, size_t row_len = 0) {
+    DeviceVec(const fpgpu_ctx* ctx, size_t n, Placement where, size_t row_len = 0, const DeviceSet* on = nullptr) {
         fpgpu_vec* raw = nullptr;
-        if (row_len) fpgpu_check(fpgpu_vec_alloc_rows(ctx, n / row_len, row_len, (int)where, &raw));
-        else fpgpu_check(fpgpu_vec_alloc(ctx, n, (int)where, &raw));
+        const fpgpu_devset* set = on ? on->raw() : nullptr;
+        if (row_len) fpgpu_check(fpgpu_vec_alloc_rows_on(ctx, set, n / row_len, row_len, (int)where, &raw));
+        else fpgpu_check(fpgpu_vec_alloc_on(ctx, set, n, (int)where, &raw));
         h_.reset(raw, [](fpgpu_vec* v) { fpgpu_vec_free(v); });
     }
     size_t size() const { return h_ ? fpgpu_vec_len(h_.get()) : 0; }

@@ -27,6 +27,40 @@ def get_devices():
     return list(arr[:n])
 
 
+class DeviceSet:
+    """An fpgpu_devset: a device list as a handle, for callers that must not depend on the process-wide
+    default list of `set_devices` (pass it as `on=` to the allocators)."""
+
+    def __init__(self, ids):
+        self._lib = _lib.load()
+        ids = list(ids)
+        arr = (ctypes.c_int * max(1, len(ids)))(*ids)
+        h = ctypes.c_void_p()
+        check(self._lib.fpgpu_devset_create(arr, len(ids), ctypes.byref(h)))
+        self._h = h
+
+    def devices(self):
+        n = self._lib.fpgpu_devset_devices(self._h, None, 0)
+        arr = (ctypes.c_int * max(1, n))()
+        self._lib.fpgpu_devset_devices(self._h, arr, n)
+        return list(arr[:n])
+
+    def free(self):
+        if getattr(self, "_h", None):
+            self._lib.fpgpu_devset_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def _set_handle(on):
+    return on._h if on is not None else None
+
+
 class DeviceVector:
     """An fpgpu_vec: `n` field elements of `field` in HBM (one device, sharded, or replicated)."""
 
@@ -34,22 +68,22 @@ class DeviceVector:
         self.field, self._h, self._lib = field, handle, field._lib
 
     @classmethod
-    def alloc(cls, field, n, placement=PLACE_CURRENT):
+    def alloc(cls, field, n, placement=PLACE_CURRENT, on=None):
         h = ctypes.c_void_p()
-        check(field._lib.fpgpu_vec_alloc(field._h, n, placement, ctypes.byref(h)))
+        check(field._lib.fpgpu_vec_alloc_on(field._h, _set_handle(on), n, placement, ctypes.byref(h)))
         return cls(field, h)
 
     @classmethod
-    def alloc_rows(cls, field, rows, cols, placement=PLACE_CURRENT):
+    def alloc_rows(cls, field, rows, cols, placement=PLACE_CURRENT, on=None):
         h = ctypes.c_void_p()
-        check(field._lib.fpgpu_vec_alloc_rows(field._h, rows, cols, placement, ctypes.byref(h)))
+        check(field._lib.fpgpu_vec_alloc_rows_on(field._h, _set_handle(on), rows, cols, placement, ctypes.byref(h)))
         return cls(field, h)
 
     @classmethod
-    def from_host(cls, field, a, placement=PLACE_CURRENT, row_len=None):
+    def from_host(cls, field, a, placement=PLACE_CURRENT, row_len=None, on=None):
         a = np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, field.n64)
-        v = cls.alloc(field, a.shape[0], placement) if not row_len else \
-            cls.alloc_rows(field, a.shape[0] // row_len, row_len, placement)
+        v = cls.alloc(field, a.shape[0], placement, on) if not row_len else \
+            cls.alloc_rows(field, a.shape[0] // row_len, row_len, placement, on)
         v.upload(a)
         return v
 
@@ -105,10 +139,10 @@ class DeviceVector:
 class DeviceIndices:
     """An fpgpu_idx: the 32-bit column indices of a SparseMatrix (rows x density), laid out like its values."""
 
-    def __init__(self, rows, density, placement=PLACE_CURRENT):
+    def __init__(self, rows, density, placement=PLACE_CURRENT, on=None):
         self._lib = _lib.load()
         h = ctypes.c_void_p()
-        check(self._lib.fpgpu_idx_alloc_rows(rows, density, placement, ctypes.byref(h)))
+        check(self._lib.fpgpu_idx_alloc_rows_on(_set_handle(on), rows, density, placement, ctypes.byref(h)))
         self._h, self.n = h, rows * density
 
     def upload(self, col_idx, first=0):

@@ -24,7 +24,10 @@
  * matrix products (lazily reduced accumulators) -- is defined for canonical
  * inputs only, as crypto-bigint's add_mod / sub_mod / neg_mod are.
  * On a little-endian host this layout is also the elements' wire format (the
- * reference's serde impls emit each element's little-endian bytes).
+ * reference's serde impls hand each element's Uint to crypto-bigint's serialiser,
+ * crypto_bigint_monty.rs:391-415, i.e. its little-endian bytes).  PARITY UNPINNED: the
+ * reference holds no byte fixture of a serialised element, and crypto-bigint is not in
+ * this tree, so tests/test_wire_format.py checks the statement against a restatement only.
  *
  * Device pointers must be 16-byte aligned (8-byte for n64 odd).  Every *_dev
  * call is asynchronous on `stream` (a hipStream_t, NULL = default stream) of the
@@ -37,9 +40,26 @@
  * copy out overlap, `out` may be `a` or `b`, and the arrays may exceed device
  * memory (a batch inversion is cut into independent ranges: an inverse does not
  * depend on the cut); the others hold whole operands in device memory they
- * allocate and free themselves.  The library
- * keeps 48 MiB of pinned host memory, and 48 MiB on each device used this way,
- * until the process ends (FPGPU_COPY_THREADS = 4; 12 MiB each per thread).
+ * allocate and free themselves.  Staging is organised in LANES (two 6 MiB pinned
+ * buffers and, on each device a lane has worked with, two 6 MiB device buffers): a
+ * transfer takes FPGPU_COPY_THREADS (default 4) free lanes per device it spans out of a
+ * process-wide table of 16, so the library keeps 48 MiB of pinned host memory and
+ * 48 MiB per device in single-threaded use, and at most 192 MiB of each when sixteen
+ * lanes have been in use at once; all of it is held until the process ends.
+ *
+ * Threads.  The reference's configs are Send + Sync and shared across rayon workers
+ * (src/lib.rs:62-65); here a context is immutable and every entry point may be called
+ * from any number of host threads at once.  There is no library-wide lock on a call
+ * path: host-buffer calls of different threads each take their own staging lanes and
+ * run side by side (a call waits only while all sixteen lanes are taken); handle
+ * operations enqueue on their list entries' streams without a lock, except that one
+ * call at a time enqueues the kernels that use an entry's scratch block (inversion,
+ * folds, the matrix products) and one all-gather / fpgpu_vec_copy protocol runs at a
+ * time.  What remains process-wide: the DEFAULT device list (fpgpu_set_devices; pass an
+ * fpgpu_devset to the *_on allocators to be independent of it), the tuning hooks, and
+ * the static array of fpgpu_batch_inv_static_dev.  Two threads that operate on the SAME
+ * vector are ordered only by the stream of the entry it lives on, in the order their
+ * calls happened to enqueue.
  */
 #ifndef FPGPU_H
 #define FPGPU_H
@@ -261,20 +281,39 @@ typedef struct fpgpu_vec fpgpu_vec;
 #define FPGPU_PLACE_SHARDED (-2)
 #define FPGPU_PLACE_REPLICATED (-3)
 
-/* count == 0 (ids may be NULL) returns to "current device alone".  Existing vectors stay valid. */
+/* count == 0 (ids may be NULL) returns to "current device alone".  Existing vectors stay valid
+ * (they keep the list they were laid out over, its streams and its communicators). */
 int fpgpu_set_devices(const int *ids, int count);
 int fpgpu_get_devices(int *ids, int capacity); /* returns the list's length (0 = not set) */
+
+/* A device list as a handle, for callers that must not depend on process-wide state (a library inside a
+ * larger program, several pipelines with different device sets in one process): the *_on allocators lay a
+ * vector out over `set` instead of the default list (set == NULL: the default list, exactly
+ * fpgpu_vec_alloc / fpgpu_vec_alloc_rows / fpgpu_idx_alloc_rows).  Everything else follows from the vector:
+ * operations, all-gathers and their RCCL communicators belong to the list the OUTPUT was laid out over.
+ * Two lists that name the same device share that device's stream(s): their work stays ordered.
+ * No counterpart in the reference (its parallel axis, rayon, has one global pool: src/matrix.rs:170-184).
+ * Destroying the handle leaves vectors laid out over it valid. */
+typedef struct fpgpu_devset fpgpu_devset;
+int fpgpu_devset_create(const int *ids, int count, fpgpu_devset **out);
+void fpgpu_devset_destroy(fpgpu_devset *set);
+int fpgpu_devset_devices(const fpgpu_devset *set, int *ids, int capacity); /* returns the list's length */
 
 int fpgpu_vec_alloc(const fpgpu_ctx *ctx, size_t n, int placement, fpgpu_vec **out);
 /* rows * cols elements; a sharded placement gives every device whole rows */
 int fpgpu_vec_alloc_rows(const fpgpu_ctx *ctx, size_t rows, size_t cols, int placement, fpgpu_vec **out);
+int fpgpu_vec_alloc_on(const fpgpu_ctx *ctx, const fpgpu_devset *set, size_t n, int placement, fpgpu_vec **out);
+int fpgpu_vec_alloc_rows_on(const fpgpu_ctx *ctx, const fpgpu_devset *set, size_t rows, size_t cols, int placement,
+                            fpgpu_vec **out);
 void fpgpu_vec_free(fpgpu_vec *v);
 size_t fpgpu_vec_len(const fpgpu_vec *v);
 int fpgpu_vec_parts(const fpgpu_vec *v);
 /* part i: its device, element range [first, first + count), device pointer and stream (any output may be NULL) */
 int fpgpu_vec_part(const fpgpu_vec *v, int i, int *device, size_t *first, size_t *count, void **dev_ptr,
                    void **stream);
-/* elements [first, first + n) <- host / -> host; both return when the host buffer is the caller's again.
+/* elements [first, first + n) <- host / -> host; both return when the host buffer is the caller's again
+ * (an upload: when the data is in device memory).  The parts of a sharded or replicated vector are
+ * transferred together, every device over its own link.
  * `host` is n * n64 words in the reference's layout (a &[MontyFieldElement] as it lies). */
 int fpgpu_vec_upload(fpgpu_vec *v, const uint64_t *host, size_t first, size_t n);
 int fpgpu_vec_download(const fpgpu_vec *v, uint64_t *host, size_t first, size_t n);
@@ -328,6 +367,7 @@ int fpgpu_vec_matmul(const fpgpu_ctx *ctx, const fpgpu_vec *A, const fpgpu_vec *
  * that holds rows, y partitioned like the rows or replicated (then all-gathered as above). */
 typedef struct fpgpu_idx fpgpu_idx;
 int fpgpu_idx_alloc_rows(size_t rows, size_t density, int placement, fpgpu_idx **out);
+int fpgpu_idx_alloc_rows_on(const fpgpu_devset *set, size_t rows, size_t density, int placement, fpgpu_idx **out);
 void fpgpu_idx_free(fpgpu_idx *idx);
 int fpgpu_idx_upload(fpgpu_idx *idx, const uint32_t *host, size_t first, size_t n);
 int fpgpu_vec_spmv(const fpgpu_ctx *ctx, const fpgpu_vec *vals, const fpgpu_idx *col_idx, size_t rows, size_t cols,
@@ -339,7 +379,7 @@ int fpgpu_vec_spmv(const fpgpu_ctx *ctx, const fpgpu_vec *vals, const fpgpu_idx 
  * FPGPU_MATMUL_GENERIC, FPGPU_SPMV_LOG2G, FPGPU_SPMV_UNROLL, FPGPU_ALLGATHER_COPY, FPGPU_COPY_THREADS, FPGPU_POW_WINDOW) are read from the environment once, when the library
  * is first used; this call sets one afterwards (process-wide; FPGPU_TUNING_DEFAULT restores the
  * library's choice).  No hook changes a result -- they pick between bit-identical paths.  Not
- * synchronised against calls running on other threads. */
+ * synchronised against calls running on other threads (set them before the threads start). */
 #define FPGPU_TUNING_DEFAULT (-0x7fffffffL - 1)
 int fpgpu_tuning_set(const char *name, long value);
 

@@ -13,6 +13,8 @@
 
 use core::ffi::CStr;
 use core::ptr::NonNull;
+use std::collections::HashMap;
+use std::sync::{Arc, Mutex, OnceLock};
 
 use crypto_primitives::{
     crypto_bigint_boxed_monty::{BoxedMontyField, BoxedMontyFieldElement},
@@ -90,6 +92,19 @@ impl Drop for GpuCtx {
     }
 }
 
+/// One `GpuCtx` per modulus for the life of the process (what INTEGRATION.md calls the cached context).
+fn cached_ctx(modulus_le: &[u64]) -> Result<Arc<GpuCtx>, GpuError> {
+    static CACHE: OnceLock<Mutex<HashMap<Vec<u64>, Arc<GpuCtx>>>> = OnceLock::new();
+    let cache = CACHE.get_or_init(|| Mutex::new(HashMap::new()));
+    let mut map = cache.lock().unwrap_or_else(|poisoned| poisoned.into_inner());
+    if let Some(ctx) = map.get(modulus_le) {
+        return Ok(Arc::clone(ctx));
+    }
+    let ctx = Arc::new(GpuCtx::new(modulus_le)?);
+    map.insert(modulus_le.to_vec(), Arc::clone(&ctx));
+    Ok(ctx)
+}
+
 /// How a config's elements turn into words and back.  The three reference adapters implement
 /// this; `BatchFieldConfig` is written once on top of it.
 pub trait GpuMarshal: FieldConfig {
@@ -104,8 +119,11 @@ pub trait GpuMarshal: FieldConfig {
     /// The exponent type's words (for `pow_batch`).
     fn integer_words(&self, e: &Self::Integer) -> Vec<u64>;
 
-    fn gpu_ctx(&self) -> Result<GpuCtx, GpuError> {
-        GpuCtx::new(&self.modulus_words())
+    /// The field's device context, made once per modulus and shared from then on (a context costs
+    /// 2 * 64 * n64 modular doublings on the host for R and R^2; it is immutable, `Send + Sync`, and
+    /// keyed by the modulus words, which determine it completely).
+    fn gpu_ctx(&self) -> Result<Arc<GpuCtx>, GpuError> {
+        cached_ctx(&self.modulus_words())
     }
     fn gather(&self, v: &[Self::Element]) -> Vec<u64> {
         let n64 = self.n64();
@@ -296,10 +314,33 @@ pub fn set_devices(ids: &[i32]) -> Result<(), GpuError> {
     check(unsafe { sys::fpgpu_set_devices(ids.as_ptr(), ids.len() as i32) })
 }
 
+/// A device list as a value (`fpgpu_devset`): lay vectors out over it with `DeviceVec::alloc_on` /
+/// `alloc_rows_on` instead of the process-wide list of `set_devices`.  Vectors keep the list alive.
+pub struct DeviceSet {
+    raw: NonNull<sys::fpgpu_devset>,
+}
+unsafe impl Send for DeviceSet {}
+unsafe impl Sync for DeviceSet {}
+impl DeviceSet {
+    pub fn new(ids: &[i32]) -> Result<Self, GpuError> {
+        let mut raw = core::ptr::null_mut();
+        // Safety: `ids` holds `len` device indices; `raw` receives an owned list or stays null.
+        check(unsafe { sys::fpgpu_devset_create(ids.as_ptr(), ids.len() as i32, &mut raw) })?;
+        Ok(Self { raw: NonNull::new(raw).expect("fpgpu_devset_create returned OK and a null list") })
+    }
+}
+impl Drop for DeviceSet {
+    fn drop(&mut self) {
+        // Safety: created by fpgpu_devset_create, destroyed once; vectors laid out over it stay valid.
+        unsafe { sys::fpgpu_devset_destroy(self.raw.as_ptr()) }
+    }
+}
+
 /// Owning handle of an `fpgpu_vec`.  Operations on it are asynchronous on the library's
 /// per-device streams; `download` and the value-returning calls synchronise.
 pub struct DeviceVec {
     raw: NonNull<sys::fpgpu_vec>,
+    n64: usize, // words per element, from the context the vector was made with: the transfers check slice lengths against it
 }
 unsafe impl Send for DeviceVec {}
 
@@ -308,13 +349,36 @@ impl DeviceVec {
         let mut raw = core::ptr::null_mut();
         // Safety: `raw` receives an owned vector or stays null.
         check(unsafe { sys::fpgpu_vec_alloc(ctx.ptr(), n, place.raw(), &mut raw) })?;
-        Ok(Self { raw: NonNull::new(raw).expect("fpgpu_vec_alloc returned OK and a null vector") })
+        Ok(Self { raw: NonNull::new(raw).expect("fpgpu_vec_alloc returned OK and a null vector"), n64: ctx.n64() })
     }
     /// `rows * cols` elements; a sharded placement gives every device whole rows.
     pub fn alloc_rows(ctx: &GpuCtx, rows: usize, cols: usize, place: Placement) -> Result<Self, GpuError> {
         let mut raw = core::ptr::null_mut();
         check(unsafe { sys::fpgpu_vec_alloc_rows(ctx.ptr(), rows, cols, place.raw(), &mut raw) })?;
-        Ok(Self { raw: NonNull::new(raw).expect("fpgpu_vec_alloc_rows returned OK and a null vector") })
+        Ok(Self { raw: NonNull::new(raw).expect("fpgpu_vec_alloc_rows returned OK and a null vector"), n64: ctx.n64() })
+    }
+    /// As `alloc`, laid out over `set` instead of the default device list.
+    pub fn alloc_on(ctx: &GpuCtx, set: &DeviceSet, n: usize, place: Placement) -> Result<Self, GpuError> {
+        let mut raw = core::ptr::null_mut();
+        check(unsafe { sys::fpgpu_vec_alloc_on(ctx.ptr(), set.raw.as_ptr(), n, place.raw(), &mut raw) })?;
+        Ok(Self { raw: NonNull::new(raw).expect("fpgpu_vec_alloc_on returned OK and a null vector"), n64: ctx.n64() })
+    }
+    /// As `alloc_rows`, laid out over `set`.
+    pub fn alloc_rows_on(ctx: &GpuCtx, set: &DeviceSet, rows: usize, cols: usize, place: Placement) -> Result<Self, GpuError> {
+        let mut raw = core::ptr::null_mut();
+        check(unsafe { sys::fpgpu_vec_alloc_rows_on(ctx.ptr(), set.raw.as_ptr(), rows, cols, place.raw(), &mut raw) })?;
+        Ok(Self { raw: NonNull::new(raw).expect("fpgpu_vec_alloc_rows_on returned OK and a null vector"), n64: ctx.n64() })
+    }
+    /// `Ok` iff `words` is exactly `n` elements and `[first, first + n)` lies inside the vector.
+    fn check_range(&self, words_len: usize, first: usize, n: usize) -> Result<(), GpuError> {
+        let want = n.checked_mul(self.n64).ok_or_else(|| GpuError::Shape("element count overflows".into()))?;
+        if words_len != want {
+            return Err(GpuError::Shape(format!("slice of {words_len} words for {n} elements of {} words", self.n64)));
+        }
+        match first.checked_add(n) {
+            Some(end) if end <= self.len() => Ok(()),
+            _ => Err(GpuError::Shape("range beyond the vector".into())),
+        }
     }
     pub fn len(&self) -> usize {
         unsafe { sys::fpgpu_vec_len(self.raw.as_ptr()) }
@@ -324,9 +388,13 @@ impl DeviceVec {
     }
     /// `words`: `n * n64` little-endian words (the output of `GpuMarshal::gather`).
     pub fn upload_words(&mut self, words: &[u64], first: usize, n: usize) -> Result<(), GpuError> {
+        self.check_range(words.len(), first, n)?;
+        // Safety: `words` holds exactly n * n64 words (checked above), the library reads no more.
         check(unsafe { sys::fpgpu_vec_upload(self.raw.as_ptr(), words.as_ptr(), first, n) })
     }
     pub fn download_words(&self, words: &mut [u64], first: usize, n: usize) -> Result<(), GpuError> {
+        self.check_range(words.len(), first, n)?;
+        // Safety: `words` holds exactly n * n64 words (checked above), the library writes no more.
         check(unsafe { sys::fpgpu_vec_download(self.raw.as_ptr(), words.as_mut_ptr(), first, n) })
     }
     pub fn sync(&self) -> Result<(), GpuError> {
@@ -555,8 +623,8 @@ where
 
 /// `BaseFieldConfig::new` with the modulus check done by the library: an even modulus is
 /// rejected by both sides with `InvalidModulus` (crypto_bigint_monty.rs:346-352).
-pub fn monty_field_with_gpu<const LIMBS: usize>(modulus: &Uint<LIMBS>) -> Result<(MontyField<LIMBS>, GpuCtx), FieldError> {
-    let ctx = GpuCtx::new(modulus.as_words())?;
+pub fn monty_field_with_gpu<const LIMBS: usize>(modulus: &Uint<LIMBS>) -> Result<(MontyField<LIMBS>, Arc<GpuCtx>), FieldError> {
+    let ctx = cached_ctx(modulus.as_words())?;
     Ok((MontyField::<LIMBS>::new(modulus)?, ctx))
 }
 
@@ -639,6 +707,18 @@ mod tests {
     fn division_by_zero_panics() {
         let f = field();
         let _ = f.div_batch(&[f.one()], &[f.zero()]);
+    }
+
+    #[test]
+    fn short_slices_are_rejected_not_read() {
+        let f = field();
+        let ctx = f.gpu_ctx().unwrap();
+        let mut d = DeviceVec::alloc(&ctx, 8, Placement::Current).unwrap();
+        assert!(matches!(d.upload_words(&[0u64; 8 * 4 - 1], 0, 8), Err(GpuError::Shape(_))));
+        assert!(matches!(d.upload_words(&[0u64; 4], 8, 1), Err(GpuError::Shape(_))));
+        let mut short = [0u64; 3];
+        assert!(matches!(d.download_words(&mut short, 0, 1), Err(GpuError::Shape(_))));
+        assert!(Arc::ptr_eq(&ctx, &f.gpu_ctx().unwrap())); // one context per modulus
     }
 
     #[test]

@@ -24,6 +24,12 @@ pub struct fpgpu_idx {
     _private: [u8; 0],
 }
 
+/// Opaque `fpgpu_devset`: a device list as a handle (the `*_on` allocators lay vectors out over it).
+#[repr(C)]
+pub struct fpgpu_devset {
+    _private: [u8; 0],
+}
+
 pub const FPGPU_OK: c_int = 0;
 /// Even or zero modulus: `FieldError::InvalidModulus` (src/field.rs:345-349).
 pub const FPGPU_ERR_INVALID_MODULUS: c_int = 1;
@@ -128,9 +134,16 @@ extern "C" {
     // ---- device-resident vectors and multi-GPU sharding (one host thread drives every device)
     pub fn fpgpu_set_devices(ids: *const c_int, count: c_int) -> c_int;
     pub fn fpgpu_get_devices(ids: *mut c_int, capacity: c_int) -> c_int;
+    pub fn fpgpu_devset_create(ids: *const c_int, count: c_int, out: *mut *mut fpgpu_devset) -> c_int;
+    pub fn fpgpu_devset_destroy(set: *mut fpgpu_devset);
+    pub fn fpgpu_devset_devices(set: *const fpgpu_devset, ids: *mut c_int, capacity: c_int) -> c_int;
     pub fn fpgpu_vec_alloc(ctx: *const fpgpu_ctx, n: usize, placement: c_int, out: *mut *mut fpgpu_vec) -> c_int;
     pub fn fpgpu_vec_alloc_rows(ctx: *const fpgpu_ctx, rows: usize, cols: usize, placement: c_int,
                                 out: *mut *mut fpgpu_vec) -> c_int;
+    pub fn fpgpu_vec_alloc_on(ctx: *const fpgpu_ctx, set: *const fpgpu_devset, n: usize, placement: c_int,
+                              out: *mut *mut fpgpu_vec) -> c_int;
+    pub fn fpgpu_vec_alloc_rows_on(ctx: *const fpgpu_ctx, set: *const fpgpu_devset, rows: usize, cols: usize,
+                                   placement: c_int, out: *mut *mut fpgpu_vec) -> c_int;
     pub fn fpgpu_vec_free(v: *mut fpgpu_vec);
     pub fn fpgpu_vec_len(v: *const fpgpu_vec) -> usize;
     pub fn fpgpu_vec_parts(v: *const fpgpu_vec) -> c_int;
@@ -167,6 +180,8 @@ extern "C" {
                             k: usize, n: usize) -> c_int;
 
     pub fn fpgpu_idx_alloc_rows(rows: usize, density: usize, placement: c_int, out: *mut *mut fpgpu_idx) -> c_int;
+    pub fn fpgpu_idx_alloc_rows_on(set: *const fpgpu_devset, rows: usize, density: usize, placement: c_int,
+                                   out: *mut *mut fpgpu_idx) -> c_int;
     pub fn fpgpu_idx_free(idx: *mut fpgpu_idx);
     pub fn fpgpu_idx_upload(idx: *mut fpgpu_idx, host: *const u32, first: usize, n: usize) -> c_int;
     pub fn fpgpu_vec_spmv(ctx: *const fpgpu_ctx, vals: *const fpgpu_vec, col_idx: *const fpgpu_idx, rows: usize, cols: usize,

@@ -87,6 +87,8 @@ _C_TO_RUST = {
     "const fpgpu_ctx *": "*const fpgpu_ctx", "fpgpu_ctx *": "*mut fpgpu_ctx", "fpgpu_ctx **": "*mut *mut fpgpu_ctx",
     "const fpgpu_vec *": "*const fpgpu_vec", "fpgpu_vec *": "*mut fpgpu_vec", "fpgpu_vec **": "*mut *mut fpgpu_vec",
     "const fpgpu_idx *": "*const fpgpu_idx", "fpgpu_idx *": "*mut fpgpu_idx", "fpgpu_idx **": "*mut *mut fpgpu_idx",
+    "const fpgpu_devset *": "*const fpgpu_devset", "fpgpu_devset *": "*mut fpgpu_devset",
+    "fpgpu_devset **": "*mut *mut fpgpu_devset",
 }
 
 

@@ -487,3 +487,126 @@ def test_host_inversion_and_division_through_the_chunk_pipeline(cpa, tuning, thr
     q, qflags = f.checked_div(a, x)
     assert np.array_equal(qflags, dflags) and np.array_equal(q, vo.download()) and np.array_equal(qflags, want_flags)
     assert np.array_equal(q[:400], o.mul(a[:400], want[:400]))
+
+
+def test_matvec_with_A_on_fewer_devices_than_the_replicated_output(cpa, devices):
+    """A placed on ONE device of a two-entry list, x and y replicated: the all-gather must take an empty range
+    from the entry that holds no rows (it once read past the end of the range table)."""
+    f, o, p, n64 = _field(cpa, "bn254_fr")
+    rows, cols = 37, 53
+    A, x = synth_elements(p, n64, rows * cols, 41), synth_elements(p, n64, cols, 42)
+    want = o.matvec(A, rows, cols, x)
+    V = cpa.DeviceVector
+    devices([0, 0])
+    for place in (0, cpa.PLACE_SHARDED):
+        vA = V.from_host(f, A, place, row_len=cols)
+        vx = V.from_host(f, x, cpa.PLACE_REPLICATED)
+        vy = V.alloc(f, rows, cpa.PLACE_REPLICATED)
+        f.matvec_vec(vA, rows, cols, vx, vy)
+        assert np.array_equal(vy.download(), want)
+        for dev, first, count, ptr, _ in vy.sync().parts():      # every copy holds the whole product
+            assert np.array_equal(_read_device(ptr, rows, n64), want)
+
+
+def test_device_sets_as_handles_are_independent_of_the_default_list(cpa, devices):
+    """fpgpu_devset: two lists in one process (three entries and one entry), the process-wide default left unset
+    and then changed underneath them; vectors keep the list they were laid out over, all-gather included."""
+    f, o, p, n64 = _field(cpa, "bn254_fr")
+    V = cpa.DeviceVector
+    s3, s1 = cpa.DeviceSet([0, 0, 0]), cpa.DeviceSet([0])
+    assert s3.devices() == [0, 0, 0] and s1.devices() == [0] and cpa.get_devices() == []
+    n, rows, cols = 10007, 61, 40
+    a, b = synth_elements(p, n64, n, 51), synth_elements(p, n64, n, 52)
+    A, x = synth_elements(p, n64, rows * cols, 53), synth_elements(p, n64, cols, 54)
+    want_y = o.matvec(A, rows, cols, x)
+    for s, nparts in ((s3, 3), (s1, 1)):
+        va, vb = V.from_host(f, a, cpa.PLACE_SHARDED, on=s), V.from_host(f, b, cpa.PLACE_SHARDED, on=s)
+        vo = V.alloc(f, n, cpa.PLACE_SHARDED, on=s)
+        assert len(va.parts()) == nparts
+        f.mul_vec(va, vb, vo)
+        devices([0, 0])                                          # the default list changes; the vectors do not care
+        f.add_vec(vo, va, vo)
+        assert np.array_equal(vo.download(), o.add(o.mul(a, b), a))
+        inv = V.alloc(f, n, cpa.PLACE_SHARDED, on=s)
+        flags = f.inv_vec(vo, inv)
+        want_inv, want_flags = o.batch_inv(o.add(o.mul(a, b), a))
+        assert np.array_equal(inv.download(), want_inv) and np.array_equal(flags, want_flags)
+        vA = V.from_host(f, A, cpa.PLACE_SHARDED, row_len=cols, on=s)
+        vx, vy = V.from_host(f, x, cpa.PLACE_REPLICATED, on=s), V.alloc(f, rows, cpa.PLACE_REPLICATED, on=s)
+        f.matvec_vec(vA, rows, cols, vx, vy)                     # all-gather over the vector's own list
+        assert np.array_equal(vy.download(), want_y)
+        devices([])
+    # a vector of the default list and a vector of a handle list do not mix silently
+    devices([0, 0])
+    vd = V.alloc(f, n, cpa.PLACE_SHARDED)
+    vs = V.from_host(f, a, cpa.PLACE_SHARDED, on=s3)
+    with pytest.raises(cpa.FpgpuError):
+        f.mul_vec(vs, vs, vd)
+    s3.free()                                                    # the handle goes; its vectors stay valid
+    assert np.array_equal(vs.download(), a)
+
+
+def test_sharded_upload_and_download_span_all_parts(cpa, devices, tuning):
+    """A sharded / replicated vector is transferred as ONE staged transfer over all of its parts (every device
+    over its own link): ragged part sizes, ranges that start and end inside parts, with and without lanes."""
+    f, o, p, n64 = _field(cpa, "bn254_fr")
+    V = cpa.DeviceVector
+    n = 5 * ((6 << 20) // 32) + 12345                              # several chunks per part
+    h = synth_elements(p, n64, n, 61)
+    for threads in (4, 1, 6):                                        # 4 is the default
+        tuning("FPGPU_COPY_THREADS", threads)
+        devices([0, 0, 0, 0])
+        v = V.from_host(f, h, cpa.PLACE_SHARDED)
+        assert np.array_equal(v.download(), h)
+        lo, cnt = n // 7 + 3, n // 2 + 11
+        assert np.array_equal(v.download(lo, cnt), h[lo:lo + cnt])
+        patch = synth_elements(p, n64, cnt, 62)
+        v.upload(patch, lo)
+        want = h.copy()
+        want[lo:lo + cnt] = patch
+        assert np.array_equal(v.download(), want)
+        r = V.from_host(f, h, cpa.PLACE_REPLICATED)
+        for dev, first, count, ptr, _ in r.sync().parts():
+            assert np.array_equal(_read_device(ptr, 4096, n64), h[:4096])
+        assert np.array_equal(r.download(), h)
+        devices([])
+
+
+def test_sixteen_host_threads_of_host_buffer_mul(cpa):
+    """The reference's configs are shared across rayon workers (src/lib.rs:62-65): sixteen host threads call the
+    host-buffer fpgpu_mul at once through one context.  Every call takes its own staging lanes (no library-wide
+    lock), results are bit-exact, and the aggregate rate is not below what ONE thread reaches alone."""
+    import threading
+    import time
+    from oracle.fp_oracle import Oracle
+    f, o = cpa.MontyField(cpa.BN254_FR, 4), Oracle(cpa.BN254_FR, 4)
+    n, T, reps = 1 << 19, 16, 3                                     # 16 MiB per operand per call
+    ins = [(synth_elements(cpa.BN254_FR, 4, n, 700 + t), synth_elements(cpa.BN254_FR, 4, n, 800 + t)) for t in range(T)]
+    for _ in range(3):                                             # the first host calls of a process run at half speed
+        f.mul(*ins[0])
+    t0 = time.perf_counter()
+    for r in range(reps * 4):
+        single = f.mul(*ins[0])
+    single_rate = reps * 4 * n / (time.perf_counter() - t0)
+    outs, errors = [None] * T, []
+
+    def work(t):
+        try:
+            for _ in range(reps):
+                outs[t] = f.mul(*ins[t])
+        except Exception as e:                                     # noqa: BLE001 - reported below
+            errors.append((t, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(T)]
+    t0 = time.perf_counter()
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    many_rate = T * reps * n / (time.perf_counter() - t0)
+    assert not errors, errors
+    assert np.array_equal(single, o.mul(*ins[0]))
+    for t in range(T):
+        assert np.array_equal(outs[t][::97], o.mul(ins[t][0][::97], ins[t][1][::97])), t
+    print("host-buffer mul: one thread %.3f G elem/s, sixteen threads %.3f G elem/s in total" % (single_rate / 1e9, many_rate / 1e9))
+    assert many_rate >= 0.9 * single_rate, (single_rate, many_rate)    # 10 % for timing noise on a shared PCIe link
