@@ -62,7 +62,7 @@ hipError_t Launch<N>::mul_chain(const fpgpu_ctx* ctx, const void* a, const void*
 
 template <int N>
 hipError_t Launch<N>::batch_inv(const fpgpu_ctx* ctx, const void* x, void* out, uint8_t* flags, size_t n, char* ws,
-                          hipStream_t s) {
+                          size_t ws_bytes, hipStream_t s) {
     const InvPlan p = make_inv_plan(ctx->n64, n);
     const FpParams<N> P = make_params<N>(ctx);
     auto blocks_for = [&](int l) { return (int)((p.count[l + 1] + kBlock - 1) / kBlock); };  // one lane per chain
@@ -70,36 +70,55 @@ hipError_t Launch<N>::batch_inv(const fpgpu_ctx* ctx, const void* x, void* out, 
     auto O = [&](int l) -> uint32_t* { return l == 0 ? (uint32_t*)out : (uint32_t*)(ws + p.o_off[l]); };
     uint8_t* poisoned = (uint8_t*)(ws + p.poison_off);
     uint32_t* any_poisoned = (uint32_t*)(ws + p.any_off);
+    // level-0 prefixes as limbs in their own array when the caller's workspace has room for it
+    const bool lp = p.bytes_lp != 0 && ws_bytes >= p.bytes_lp && tuning().inv_lp != 0;
+    uint32_t* praw = lp ? (uint32_t*)(ws + p.lp_off) : nullptr;
     if (hipError_t e = hipMemsetAsync(any_poisoned, 0, sizeof(uint32_t), s); e != hipSuccess) return e;
+    // the last stored level and the exact inversions share one kernel when that level's chains are short
+    const bool fused = p.fused_top && tuning().inv_fuse_top != 0;
+    const int sweeps = fused ? p.levels - 1 : p.levels;
     // up-sweeps
-    for (int l = 0; l < p.levels; l++) {
+    for (int l = 0; l < sweeps; l++) {
         int blocks = blocks_for(l);
         uint32_t* totals = (uint32_t*)(ws + p.x_off[l + 1]);
-        if (l == 0)
-            hipLaunchKernelGGL((k_binv_up<N, true>), dim3(blocks), dim3(kBlock), 0, s, X(0), O(0), totals,
+        if (l == 0 && lp)
+            hipLaunchKernelGGL((k_binv_up<N, true, true>), dim3(blocks), dim3(kBlock), 0, s, X(0), O(0), praw, totals,
                                flags, p.count[0], p.c[0], P);
+        else if (l == 0)
+            hipLaunchKernelGGL((k_binv_up<N, true, false>), dim3(blocks), dim3(kBlock), 0, s, X(0), O(0),
+                               (uint32_t*)nullptr, totals, flags, p.count[0], p.c[0], P);
         else
-            hipLaunchKernelGGL((k_binv_up<N, false>), dim3(blocks), dim3(kBlock), 0, s, X(l), O(l), totals,
-                               (uint8_t*)nullptr, p.count[l], p.c[l], P);
+            hipLaunchKernelGGL((k_binv_up<N, false, false>), dim3(blocks), dim3(kBlock), 0, s, X(l), O(l),
+                               (uint32_t*)nullptr, totals, (uint8_t*)nullptr, p.count[l], p.c[l], P);
     }
-    // top: exact inverses of the remaining totals, in place
-    {
+    if (fused) {
+        // top: chains over the last level's elements, exact inverse of each chain total, walk back: O(l) = inverses of X(l)
+        const int l = p.levels - 1;
+        const size_t chains = p.count[l + 1];
+        const int blocks = (int)((chains + kTopChainBlock - 1) / kTopChainBlock);
+        hipLaunchKernelGGL((k_binv_top_chain<N>), dim3(blocks), dim3(kTopChainBlock), 0, s, X(l), O(l), poisoned,
+                           any_poisoned, p.count[l], p.c[l], P);
+    } else {
+        // top: exact inverses of the remaining totals, in place
         size_t c = p.count[p.levels];
         int blocks = (int)((c + kBlock - 1) / kBlock);
         hipLaunchKernelGGL((k_binv_top<N>), dim3(blocks), dim3(kBlock), 0, s, (uint32_t*)(ws + p.x_off[p.levels]),
                            poisoned, any_poisoned, c, P);
     }
     // down-sweeps
-    for (int l = p.levels - 1; l >= 0; l--) {
+    for (int l = sweeps - 1; l >= 0; l--) {
         int blocks = blocks_for(l);
         const uint32_t* inv_totals =
             (l + 1 == p.levels) ? (const uint32_t*)(ws + p.x_off[l + 1]) : (const uint32_t*)O(l + 1);
-        if (l == 0)
-            hipLaunchKernelGGL((k_binv_down<N, true>), dim3(blocks), dim3(kBlock), 0, s, X(0), O(0),
-                               inv_totals, p.count[0], p.c[0], P);
+        if (l == 0 && lp)
+            hipLaunchKernelGGL((k_binv_down<N, true, true>), dim3(blocks), dim3(kBlock), 0, s, X(0), O(0),
+                               (const uint32_t*)praw, inv_totals, p.count[0], p.c[0], P);
+        else if (l == 0)
+            hipLaunchKernelGGL((k_binv_down<N, true, false>), dim3(blocks), dim3(kBlock), 0, s, X(0), O(0),
+                               (const uint32_t*)nullptr, inv_totals, p.count[0], p.c[0], P);
         else
-            hipLaunchKernelGGL((k_binv_down<N, false>), dim3(blocks), dim3(kBlock), 0, s, X(l), O(l),
-                               inv_totals, p.count[l], p.c[l], P);
+            hipLaunchKernelGGL((k_binv_down<N, false, false>), dim3(blocks), dim3(kBlock), 0, s, X(l), O(l),
+                               (const uint32_t*)nullptr, inv_totals, p.count[l], p.c[l], P);
     }
     // composite-modulus safety net (a no-op unless a top-level total was not invertible)
     InvChains chains{};

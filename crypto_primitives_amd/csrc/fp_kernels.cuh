@@ -337,57 +337,108 @@ __device__ __forceinline__ bool mont_inv_gcd(uint32_t (&out)[N], const uint32_t 
 // version gave each workgroup its own tile of 256 C consecutive elements; in lockstep those
 // tile strides land on a fraction of the channels, and the level-0 sweeps ran at 4.2 TB/s.)
 //   k_binv_up:   prefix[e] = product of the chain's earlier elements (zeros taken
-//                as one), total[c] = product of the whole chain.
+//                as a unit), total[c] = product of the whole chain.
 //   (recurse on the totals until few remain, invert those with the GCD kernel)
 //   k_binv_down: walks each chain backwards with the inverted total.
 // Chain index of element e at a level with M chains: e % M.
-// The running products are Chain<N> values (fp_unsat.cuh): from N = 6 limbs on they live in
-// unsaturated 29-bit limbs and, where the modulus leaves two spare bits, in [0, 2p): prefixes
-// and totals are then stored unreduced (they fit the container), and only the results
-// k_binv_down writes are canonical.  Both kernels load the next element of the chain before they
-// multiply by the current one, so a wave always has a load in flight behind its arithmetic.
-template <int N, bool LEVEL0>
+// The running products are Chain<N> values (fp_unsat.cuh) multiplied in the Montgomery domain of
+// R' = 2^(29 L) from N = 6 limbs on (Chain::mulr: no pre-shifted operand, values in [0, 2p) for every
+// modulus; the derivation is there), so prefixes and totals are stored unreduced where they fit the
+// container and only the results k_binv_down writes are canonical.  A chain of c elements costs
+// 3 (c - 1) multiplications: the running product STARTS as the first element (no multiplication by one,
+// no prefix stored for it), and the walk back ends with out[first] = the running inverse itself.
+// Both kernels load the next element of the chain before they multiply by the current one, so a wave
+// always has a load in flight behind its arithmetic.
+// LP ("limb prefixes", level 0 only): prefixes go to a separate array `praw` in the chain's raw form
+// (RawForm<N>::STRIDE 32-bit words per element: the 29-bit limbs as they are), which removes the limbs -> words
+// conversion here and the words -> limbs one in k_binv_down at 4 * (STRIDE - N) more bytes per element each way.
+template <int N>
+struct RawForm {   // a running product as its limbs in memory: RAW 32-bit words, padded to whole 8-byte pairs
+    static constexpr int RAW = Chain<N>::RAW, STRIDE = (RAW + 1) & ~1;
+};
+template <int N>
+__device__ __forceinline__ void load_raw(uint32_t (&t)[Chain<N>::RAW], const uint32_t* __restrict__ base, size_t e) {
+    constexpr int R = RawForm<N>::RAW, S = RawForm<N>::STRIDE;
+    // tiles of 64 consecutive elements, limb pair i of the tile's elements side by side: a wave's access is one 512-byte row
+    const uint2* p = reinterpret_cast<const uint2*>(base) + (e >> 6) * (size_t)(S / 2) * 64 + (e & 63);
+#pragma unroll
+    for (int i = 0; i < S / 2; i++) {
+        const uint2 q = p[(size_t)i * 64];
+        t[2 * i] = q.x;
+        if (2 * i + 1 < R) t[2 * i + 1] = q.y;
+    }
+}
+template <int N>
+__device__ __forceinline__ void store_raw(uint32_t* __restrict__ base, size_t e, const uint32_t (&t)[Chain<N>::RAW]) {
+    constexpr int R = RawForm<N>::RAW, S = RawForm<N>::STRIDE;
+    uint2* p = reinterpret_cast<uint2*>(base) + (e >> 6) * (size_t)(S / 2) * 64 + (e & 63);
+#pragma unroll
+    for (int i = 0; i < S / 2; i++) p[(size_t)i * 64] = make_uint2(t[2 * i], 2 * i + 1 < R ? t[2 * i + 1] : 0u);
+}
+
+template <int N, bool LEVEL0, bool LP>
 __global__ __launch_bounds__(kBlock) void k_binv_up(const uint32_t* __restrict__ x, uint32_t* __restrict__ prefix,
-                                                    uint32_t* __restrict__ totals, uint8_t* __restrict__ zero_flags,
-                                                    size_t n, const int C, const FpParams<N> P) {
+                                                    uint32_t* __restrict__ praw, uint32_t* __restrict__ totals,
+                                                    uint8_t* __restrict__ zero_flags, size_t n, const int C,
+                                                    const FpParams<N> P) {
     const size_t M = (n + C - 1) / C;   // chains at this level
     const size_t chain = (size_t)blockIdx.x * kBlock + threadIdx.x;
     size_t e = chain;
     if (chain >= M) return;
     Chain<N> run(P);
     uint32_t w[N], v[N], vn[N];
-    set_limbs<N>(w, P.one);
-    run.set(w);
     load_elem<N>(v, x, e);
+    {   // the first element: the running product starts as it.  Level 0 takes a zero as a unit (it is flagged
+        // and its slot gets 0): ANY unit will do -- the other elements' inverses do not depend on it -- so R mod p.
+        const bool more = 1 < C && e + M < n;
+        load_elem<N>(vn, x, more ? e + M : e);
+        if constexpr (LEVEL0) {
+            const bool z = is_zero<N>(v);
+            if (zero_flags) zero_flags[e] = z ? 1 : 0;
+#pragma unroll
+            for (int l = 0; l < N; l++) v[l] = z ? P.one[l] : v[l];
+        }
+        run.set(v);
+#pragma unroll
+        for (int l = 0; l < N; l++) v[l] = vn[l];
+        e += M;
+    }
 #pragma unroll 1
-    for (int k = 0; k < C && e < n; k++, e += M) {
+    for (int k = 1; k < C && e < n; k++, e += M) {
         // next element of the chain (the current one again at the end: an unconditional load
         // keeps the loop free of a conditional register merge)
         const bool more = k + 1 < C && e + M < n;
         load_elem<N>(vn, x, more ? e + M : e);
-        run.get(w);
-        store_elem<N>(prefix, e, w);
+        if constexpr (LP) {
+            uint32_t t[Chain<N>::RAW];
+            run.get_raw(t);
+            store_raw<N>(praw, e, t);
+        } else {
+            run.get_words(w);
+            store_elem<N>(prefix, e, w);
+        }
         bool z = is_zero<N>(v);
         if constexpr (LEVEL0) {
             if (zero_flags) zero_flags[e] = z ? 1 : 0;
         }
-        // Level 0 takes a zero as one (it is flagged, its slot gets 0).  Above level 0 a
-        // zero total (composite modulus only) must poison its group: keep multiplying so
-        // the zero reaches the top, where the GCD inverse rejects it.
-        if (!z || !LEVEL0) run.mul(v);
+        // Level 0 skips a zero (flagged, its slot gets 0).  Above level 0 a zero total (composite modulus
+        // only) must poison its group: keep multiplying so the zero reaches the top, where the GCD inverse
+        // rejects it.
+        if (!z || !LEVEL0) run.mulr(v);
 #pragma unroll
         for (int l = 0; l < N; l++) v[l] = vn[l];
     }
-    run.get(w);
+    run.get_words(w);
     store_elem<N>(totals, chain, w);
 }
 
-// inv_totals[chain] holds the inverse of the chain total; poisoned[] (may be null
-// below level 0 bookkeeping) is handled by the fallback kernel, not here.
-template <int N, bool LEVEL0>
+// inv_totals[chain] holds R^2 / (the chain total); poisoned[] is handled by the fallback kernel, not here.
+template <int N, bool LEVEL0, bool LP>
 __global__ __launch_bounds__(kBlock) void k_binv_down(const uint32_t* __restrict__ x, uint32_t* __restrict__ out,
+                                                      const uint32_t* __restrict__ praw,
                                                       const uint32_t* __restrict__ inv_totals, size_t n, const int C,
                                                       const FpParams<N> P) {
+    constexpr int RW = LP ? Chain<N>::RAW : N;
     const size_t M = (n + C - 1) / C;   // chains at this level
     const size_t chain = (size_t)blockIdx.x * kBlock + threadIdx.x;
     const size_t first = chain;
@@ -395,17 +446,21 @@ __global__ __launch_bounds__(kBlock) void k_binv_down(const uint32_t* __restrict
     // number of elements in this chain (at most C, because C M >= n)
     const size_t cnt = (n - first + M - 1) / M;
     Chain<N> run(P);
-    uint32_t w[N], v[N], pre[N], vn[N], pn[N];
+    uint32_t w[N], v[N], vn[N], pre[RW], pn[RW];
+    auto load_pre = [&](uint32_t (&t)[RW], size_t e) {
+        if constexpr (LP) load_raw<N>(t, praw, e);
+        else load_elem<N>(t, out, e);   // the exclusive prefix k_binv_up left in the output slot
+    };
     load_elem<N>(w, inv_totals, chain);
     run.set(w);
     load_elem<N>(v, x, first + (cnt - 1) * M);
-    load_elem<N>(pre, out, first + (cnt - 1) * M);  // exclusive prefix written by k_binv_up
+    if (cnt > 1) load_pre(pre, first + (cnt - 1) * M);
 #pragma unroll 1
-    for (size_t k = cnt; k-- > 0;) {
+    for (size_t k = cnt; k-- > 1;) {
         const size_t e = first + k * M;
-        const size_t en = k > 0 ? e - M : e;   // next element down the chain (see k_binv_up)
+        const size_t en = e - M;               // next element down the chain
         load_elem<N>(vn, x, en);
-        load_elem<N>(pn, out, en);
+        load_pre(pn, k > 1 ? en : e);          // the first element has no prefix: read a valid slot again
         bool z = LEVEL0 && is_zero<N>(v);
         if (z) {
 #pragma unroll
@@ -414,13 +469,82 @@ __global__ __launch_bounds__(kBlock) void k_binv_down(const uint32_t* __restrict
         } else {
             // Above level 0 a zero total only occurs in a poisoned group (composite
             // modulus); whatever is written below it is recomputed by k_binv_fallback.
-            run.mul_to(w, pre);
+            if constexpr (LP) run.mulr_raw_to(w, pre);
+            else run.mulr_to(w, pre);
             store_elem<N>(out, e, w);
-            run.mul(v);
+            run.mulr(v);
         }
 #pragma unroll
-        for (int l = 0; l < N; l++) { v[l] = vn[l]; pre[l] = pn[l]; }
+        for (int l = 0; l < N; l++) v[l] = vn[l];
+#pragma unroll
+        for (int l = 0; l < RW; l++) pre[l] = pn[l];
     }
+    // the first element of the chain: what is left of the running inverse is its inverse
+    if (LEVEL0 && is_zero<N>(v)) {
+#pragma unroll
+        for (int l = 0; l < N; l++) w[l] = 0;
+    } else {
+        run.get_canonical(w);
+    }
+    store_elem<N>(out, first, w);
+}
+
+// The last stored level and the exact inversions in ONE kernel (no separate up- and down-sweep over the
+// totals, no prefixes through HBM): lane c multiplies its chain {c + k M : k < cnt <= C} of the level's
+// elements together, keeping the running products in LDS (raw form, one column per lane, no barrier),
+// inverts the chain total exactly and walks back.  The level is small by construction (at most one wave
+// per SIMD), so every lane's work is pure latency either way; this takes two launches and two HBM round
+// trips of latency out of it.  Zero totals are not skipped here (composite moduli: they poison the group).
+constexpr int kTopChainBlock = 64;   // one wave per workgroup: (C - 1) * RAW * 256 bytes of LDS each, four workgroups per CU
+constexpr int kTopChainMaxC = 8;
+template <int N>
+__global__ __launch_bounds__(kTopChainBlock) void k_binv_top_chain(const uint32_t* __restrict__ x, uint32_t* __restrict__ out,
+                                                           uint8_t* __restrict__ poisoned,
+                                                           uint32_t* __restrict__ any_poisoned, size_t n, const int C,
+                                                           const FpParams<N> P) {
+    constexpr int RW = Chain<N>::RAW;
+    // [C - 1][RW][lane], padded to 40 KiB: at most four of these one-wave workgroups then fit a CU's 160 KiB, so
+    // 2^16 chains spread as one wave per SIMD over the whole chip instead of piling up on some CUs
+    constexpr int kWords = (kTopChainMaxC - 1) * RW * kTopChainBlock > 10240 ? (kTopChainMaxC - 1) * RW * kTopChainBlock : 10240;
+    __shared__ uint32_t binv_lds[kWords];
+    const size_t M = (n + C - 1) / C;
+    const size_t chain = (size_t)blockIdx.x * kTopChainBlock + threadIdx.x;
+    if (chain >= M) return;   // no barrier below: a lane only ever touches its own LDS column
+    const int cnt = (int)((n - chain + M - 1) / M);
+    uint32_t* col = binv_lds + threadIdx.x;
+    Chain<N> run(P);
+    uint32_t w[N], v[N], t[RW];
+    load_elem<N>(v, x, chain);
+    run.set(v);
+#pragma unroll 1
+    for (int k = 1; k < cnt; k++) {
+        load_elem<N>(v, x, chain + (size_t)k * M);
+        run.get_raw(t);
+#pragma unroll
+        for (int l = 0; l < RW; l++) col[((k - 1) * RW + l) * kTopChainBlock] = t[l];
+        run.mulr(v);
+    }
+    run.get_canonical(w);
+    uint32_t r[N];
+    const bool ok = mont_inv_gcd<N>(r, w, P);
+    if (!ok) {
+#pragma unroll
+        for (int l = 0; l < N; l++) r[l] = 0;
+        any_poisoned[0] = 1;   // benign race: every writer stores the same value
+    }
+    poisoned[chain] = ok ? 0 : 1;
+    run.set(r);
+#pragma unroll 1
+    for (int k = cnt; k-- > 1;) {
+        load_elem<N>(v, x, chain + (size_t)k * M);
+#pragma unroll
+        for (int l = 0; l < RW; l++) t[l] = col[((k - 1) * RW + l) * kTopChainBlock];
+        run.mulr_raw_to(w, t);
+        store_elem<N>(out, chain + (size_t)k * M, w);
+        run.mulr(v);
+    }
+    run.get_canonical(w);
+    store_elem<N>(out, chain, w);
 }
 
 // Top level: invert each remaining total with the exact GCD inverse.  A total that

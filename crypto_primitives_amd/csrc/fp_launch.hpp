@@ -46,6 +46,9 @@ struct InvPlan {
     size_t poison_off = 0;
     size_t any_off = 0;                      // one word: did any top-level inversion fail
     size_t bytes = 0;
+    bool fused_top = false;                  // the last level's sweeps and the exact inversions run as one kernel (k_binv_top_chain)
+    size_t lp_off = 0;                       // level-0 prefixes as limbs (k_binv_up<.., LP>): their array sits behind `bytes`
+    size_t bytes_lp = 0;                     // workspace size with that array; 0 where limbs are the words (narrow fields)
 };
 InvPlan make_inv_plan(uint32_t n64, size_t n);
 // Workspace of the matrix-core mat-vec (fp_matvec_mfma.cuh): flag, column sums, the 64-bit
@@ -109,6 +112,9 @@ int grid_for(size_t n);
 struct Tuning {
     long grid_cap = 0;        // FPGPU_GRID_CAP: workgroup cap of the streaming kernels
     long inv_c = 0;           // FPGPU_INV_C: chain length of every batch-inversion level
+    long inv_c0 = 0;          // FPGPU_INV_C0: chain length of level 0 only
+    long inv_fuse_top = -1;   // FPGPU_INV_FUSE_TOP: 0 = the last level as separate up / top / down kernels
+    long inv_lp = -1;         // FPGPU_INV_LP: 0 = level-0 prefixes as words in the output array even when the workspace has room for limbs
     long matvec_mfma = -1;    // FPGPU_MATVEC_MFMA: 0 forces the VALU mat-vec
     long matvec_ksplit = 0;   // FPGPU_MATVEC_KSPLIT: column parts per row block (matrix-core mat-vec)
     long matvec_t = 0;        // FPGPU_MATVEC_T: products per pass of the VALU mat-vec
@@ -130,7 +136,7 @@ struct Launch {
                             hipStream_t s);
     static hipError_t mul_chain(const fpgpu_ctx* ctx, const void* a, const void* b, void* out, size_t n, uint32_t iters,
                           hipStream_t s);
-    static hipError_t batch_inv(const fpgpu_ctx* ctx, const void* x, void* out, uint8_t* flags, size_t n, char* ws,
+    static hipError_t batch_inv(const fpgpu_ctx* ctx, const void* x, void* out, uint8_t* flags, size_t n, char* ws, size_t ws_bytes,
                           hipStream_t s);
     static hipError_t matvec(const fpgpu_ctx* ctx, const void* A, size_t rows, size_t cols, const void* x, void* y,
                        void* workspace, size_t workspace_bytes,

@@ -363,6 +363,13 @@ struct Chain<N, false> {
         for (int l = 0; l < N; l++) o[l] = w[l];
     }
     __device__ __forceinline__ void mul_op(const Op& o) { mul(o); }
+    // -- the batch inversion's view (see Chain<N, true>): here R' = R and the raw form is the words themselves
+    static constexpr int RAW = N;
+    __device__ __forceinline__ void mulr(const uint32_t (&w)[N]) { mul(w); }
+    __device__ __forceinline__ void get_raw(uint32_t (&t)[N]) const { get(t); }
+    __device__ __forceinline__ void get_words(uint32_t (&w)[N]) const { get(w); }
+    __device__ __forceinline__ void mulr_raw_to(uint32_t (&out)[N], const uint32_t (&t)[N]) const { mont_mul<N>(out, v, t, P); }
+    __device__ __forceinline__ void mulr_to(uint32_t (&out)[N], const uint32_t (&w)[N]) const { mont_mul<N>(out, v, w, P); }
 };
 
 template <int N>
@@ -422,6 +429,63 @@ struct Chain<N, true> {
     typedef uint32_t Op[L];
     static __device__ __forceinline__ void prep(Op& o, const uint32_t (&w)[N]) { uload_shifted<N>(o, w); }
     __device__ __forceinline__ void mul_op(const Op& o) { mul_limbs(o); }
+
+    // -- the batch inversion's view: products in the Montgomery domain of R' = 2^(29 L) ------------------
+    // Montgomery's trick only needs SOME group operation on the representatives whose inverse the top level
+    // can supply.  With a (x) b = a b / R' no operand is pre-shifted, every modulus of the container is lazy
+    // (R' >= 4p: values stay in [0, 2p) with no conditional subtraction, tight moduli included), and a
+    // running product can be stored and reloaded as its limbs ("raw" form) with no conversion at all.  The
+    // chain totals differ from the R-domain ones by powers of R / R', but the top level returns R^2 / T for
+    // whatever T it is given (MontyField::inv on the representative), and walking back down with (x) turns
+    // that into R^2 / x for every element: by induction I_k = R^2 / t_k implies I_k (x) t_(k-1) = R^2 / x_k and
+    // I_k (x) x_k = R^2 / t_(k-1) for t_k = t_(k-1) (x) x_k.  The outputs are the same canonical residues.
+    static constexpr int RAW = L;
+    static_assert(UF<N>::SH >= 2, "R' >= 4p needs two spare bits above the container");
+    __device__ __forceinline__ void mulr_limbs(const uint32_t (&s)[L]) {
+        uint32_t t[L];
+        umul<N>(t, v, s, U);
+#pragma unroll
+        for (int l = 0; l < L; l++) v[l] = t[l];
+    }
+    __device__ __forceinline__ void mulr(const uint32_t (&w)[N]) {
+        uint32_t s[L];
+        uload<N>(s, w);
+        mulr_limbs(s);
+    }
+    __device__ __forceinline__ void get_raw(uint32_t (&t)[L]) const {
+#pragma unroll
+        for (int l = 0; l < L; l++) t[l] = v[l];
+    }
+    // the running value as words that hold it: as it is where 2p <= R, else brought below p first
+    __device__ __forceinline__ void get_words(uint32_t (&w)[N]) const {
+        if (lazy) get(w);
+        else get_canonical(w);
+    }
+    // canonical words of a value below 2p given as limbs
+    __device__ __forceinline__ void finish(uint32_t (&out)[N], uint32_t (&t)[L]) const {
+        if (lazy) {   // 2p < R: the conditional subtraction is cheaper on the words (see mul_to)
+            uint32_t x[N], d[N];
+            ustore<N>(x, t);
+            const uint32_t below = sub_limbs_s<N>(d, x, pw);
+#pragma unroll
+            for (int l = 0; l < N; l++) out[l] = below ? x[l] : d[l];
+        } else {
+            ucanon<N>(t, U);
+            ustore<N>(out, t);
+        }
+    }
+    // out = canonical(running value (x) t), t in raw form
+    __device__ __forceinline__ void mulr_raw_to(uint32_t (&out)[N], const uint32_t (&t)[L]) const {
+        uint32_t r[L];
+        umul<N>(r, v, t, U);
+        finish(out, r);
+    }
+    // out = canonical(running value (x) w), w as words
+    __device__ __forceinline__ void mulr_to(uint32_t (&out)[N], const uint32_t (&w)[N]) const {
+        uint32_t s[L];
+        uload<N>(s, w);
+        mulr_raw_to(out, s);
+    }
 };
 
 // ---- PowLadder<N>: square-and-multiply state for k_pow ------------------------------------

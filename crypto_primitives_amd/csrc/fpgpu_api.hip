@@ -110,6 +110,8 @@ static const TuningEntry kTuningEntries[] = {
     {"FPGPU_MATMUL_GENERIC", &Tuning::matmul_generic}, {"FPGPU_SPMV_LOG2G", &Tuning::spmv_log2g},
     {"FPGPU_ALLGATHER_COPY", &Tuning::allgather_copy}, {"FPGPU_COPY_THREADS", &Tuning::copy_threads},
     {"FPGPU_POW_WINDOW", &Tuning::pow_window},         {"FPGPU_SPMV_UNROLL", &Tuning::spmv_unroll},
+    {"FPGPU_INV_C0", &Tuning::inv_c0},                 {"FPGPU_INV_FUSE_TOP", &Tuning::inv_fuse_top},
+    {"FPGPU_INV_LP", &Tuning::inv_lp},
 };
 static Tuning g_tuning_defaults;
 static Tuning g_tuning;
@@ -145,6 +147,7 @@ InvPlan make_inv_plan(uint32_t n64, size_t n) {
         int len = kInvCMin;
         while (len < kInvCMax && c / (2 * (size_t)len) >= kInvLanesWanted) len *= 2;
         if (const long v = tuning().inv_c; v >= 2 && v <= 1024) len = (int)v;  // tuning / tests
+        if (const long v = tuning().inv_c0; p.levels == 0 && v >= 2 && v <= 1024) len = (int)v;
         p.c[p.levels] = len;
         p.count[p.levels + 1] = (c + len - 1) / len;   // chains of `len` elements, see k_binv_up
         p.levels++;
@@ -156,6 +159,17 @@ InvPlan make_inv_plan(uint32_t n64, size_t n) {
     p.poison_off = take(p.count[p.levels]);
     p.any_off = take(sizeof(uint32_t));
     p.bytes = off;
+    // the last stored level rides in the top kernel when its chains are short (then that level's own prefix
+    // array O_l is still what the level below reads its inverted totals from; X_(l+1) goes unused)
+    p.fused_top = p.levels >= 2 && p.c[p.levels - 1] <= 8;
+    // level-0 prefixes as 29-bit limbs, 4 * STRIDE bytes each (fp_kernels.cuh RawForm).  Measured (tools/exp_binv_ab.py,
+    // 2^24 elements): it pays from 384 bits on (BLS12-381 1.065 -> 1.047 ms, 512 bits 1.62 -> 1.57), where the limb form
+    // is 12-17 % larger than the words; at 256 bits it is 25 % larger and loses (0.618 -> 0.638 ms)
+    if (n64 >= 6) {
+        const size_t n32 = 2 * (size_t)n64, raw = (32 * n32 + 28) / 29, stride = (raw + 1) & ~(size_t)1;
+        p.lp_off = take(((n + 63) / 64 * 64) * stride * 4);   // whole tiles of 64 elements
+        p.bytes_lp = off;
+    }
     return p;
 }
 
@@ -309,6 +323,12 @@ size_t fpgpu_batch_inv_workspace_bytes(const fpgpu_ctx* ctx, size_t n) {
     return make_inv_plan(ctx->n64, n).bytes;
 }
 
+size_t fpgpu_batch_inv_fast_workspace_bytes(const fpgpu_ctx* ctx, size_t n) {
+    if (!ctx || n == 0) return 0;
+    const InvPlan p = make_inv_plan(ctx->n64, n);
+    return p.bytes_lp ? p.bytes_lp : p.bytes;
+}
+
 int fpgpu_batch_inv_dev(const fpgpu_ctx* ctx, const void* x, void* out, uint8_t* zero_flags, size_t n,
                         void* workspace, size_t workspace_bytes, void* stream) {
     CHECK(check_common(ctx, n));
@@ -320,7 +340,7 @@ int fpgpu_batch_inv_dev(const fpgpu_ctx* ctx, const void* x, void* out, uint8_t*
     if (workspace_bytes < fpgpu_batch_inv_workspace_bytes(ctx, n))
         return fail(FPGPU_ERR_SHAPE, "batch_inv: workspace too small");
     hipStream_t s = (hipStream_t)stream;
-    DISPATCH_N64(ctx->n64, HIP_TRY(Launch<N>::batch_inv(ctx, x, out, zero_flags, n, (char*)workspace, s)));
+    DISPATCH_N64(ctx->n64, HIP_TRY(Launch<N>::batch_inv(ctx, x, out, zero_flags, n, (char*)workspace, workspace_bytes, s)));
     HIP_TRY(hipGetLastError());
     return FPGPU_OK;
 }
@@ -355,7 +375,7 @@ int fpgpu_batch_inv_static_dev(const fpgpu_ctx* ctx, const void* x, void* out, u
     hipStream_t s = (hipStream_t)stream;
     // the launcher clears what must start at zero (the poison word); everything else in the
     // scratch is written before it is read, so the previous call's contents do not matter
-    DISPATCH_N64(ctx->n64, HIP_TRY(Launch<N>::batch_inv(ctx, x, out, zero_flags, n, (char*)scratch, s)));
+    DISPATCH_N64(ctx->n64, HIP_TRY(Launch<N>::batch_inv(ctx, x, out, zero_flags, n, (char*)scratch, FPGPU_STATIC_SCRATCH_BYTES, s)));
     HIP_TRY(hipGetLastError());
     return FPGPU_OK;
 }
@@ -631,7 +651,7 @@ int fpgpu_batch_inv(const fpgpu_ctx* ctx, const uint64_t* x, uint64_t* out, uint
     CHECK(require_device());
     if (const int rc = inv_or_div_streamed(ctx, nullptr, x, out, zero_flags, n); rc != FPGPU_ERR_UNSUPPORTED) return rc;
     size_t bytes = n * ctx->n64 * 8;
-    size_t wsb = fpgpu_batch_inv_workspace_bytes(ctx, n);
+    size_t wsb = fpgpu_batch_inv_fast_workspace_bytes(ctx, n);
     DevBuf dx, dout, dflags, ws;
     CHECK(dx.alloc(bytes));
     CHECK(dout.alloc(bytes));
@@ -652,7 +672,7 @@ int fpgpu_div(const fpgpu_ctx* ctx, const uint64_t* a, const uint64_t* b, uint64
     CHECK(require_device());
     if (const int rc = inv_or_div_streamed(ctx, a, b, out, zero_flags, n); rc != FPGPU_ERR_UNSUPPORTED) return rc;
     size_t bytes = n * ctx->n64 * 8;
-    size_t wsb = fpgpu_batch_inv_workspace_bytes(ctx, n);
+    size_t wsb = fpgpu_batch_inv_fast_workspace_bytes(ctx, n);
     DevBuf da, db, dout, dflags, ws;
     CHECK(da.alloc(bytes));
     CHECK(db.alloc(bytes));

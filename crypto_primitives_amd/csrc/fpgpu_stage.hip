@@ -177,17 +177,25 @@ struct LaneSet {
     int width() const { return (int)lanes.size(); }
 };
 
-// Takes up to `want` free lanes (at least one; waits while every lane is taken, and leaves a share for
-// the transfers waiting beside it).  FPGPU_ERR_UNSUPPORTED: staging is not available in this process
-// (no pinned memory) -- the caller takes the plain path.
+// Takes up to `want` lanes (at least one) while no more than `want` are busy in the whole process: more
+// copy threads than that only contend for the link and the memory bus (fpgpu_mul over 2^22 elements with
+// 2 / 3 / 4 / 5 / 6 / 8 lanes: 9.4 / 7.2 / 6.5 / 7.1 / 7.4 / 7.6 ms), so sixteen host threads calling at once
+// share the four lanes one caller would use -- side by side when each gets one, one after the other when
+// the first took them all -- instead of starting sixty-four memcpy threads.  A transfer that spans g devices
+// asks for (and is capped at) g times as many.  Waits while the cap is reached, and leaves a share for the
+// transfers waiting beside it.  FPGPU_ERR_UNSUPPORTED: staging is not available in this process (no pinned
+// memory) -- the caller takes the plain path.
 int acquire_lanes(int want, LaneSet* out) {
     std::unique_lock<std::mutex> l(g_stage.mu);
     if (!g_stage.pool) g_stage.pool = new (std::nothrow) TaskPool();
     if (!g_stage.pool) return FPGPU_ERR_UNSUPPORTED;
-    auto free_lanes = [] {
-        int f = 0;
-        for (Lane& L : g_stage.lanes) f += !L.busy && !L.dead;
-        return f;
+    auto free_lanes = [want] {
+        int f = 0, busy = 0;
+        for (Lane& L : g_stage.lanes) {
+            f += !L.busy && !L.dead;
+            busy += L.busy;
+        }
+        return std::min(f, std::max(0, want - busy));
     };
     for (;;) {
         if (g_stage.host_unavailable) return FPGPU_ERR_UNSUPPORTED;

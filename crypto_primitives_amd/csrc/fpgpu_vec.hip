@@ -885,7 +885,7 @@ static int vec_inv_or_div(const fpgpu_ctx* ctx, const fpgpu_vec* a, const fpgpu_
         if (a) CHECK(operand_ptr(a, out, pi, "a", &pa));
         if (o.count == 0) continue;
         HIP_TRY(hipSetDevice(o.slot->device));
-        const size_t wsb = (fpgpu_batch_inv_workspace_bytes(ctx, o.count) + 255) & ~(size_t)255;
+        const size_t wsb = (fpgpu_batch_inv_fast_workspace_bytes(ctx, o.count) + 255) & ~(size_t)255;
         std::lock_guard<std::mutex> lock(o.slot->mu);   // workspace and flags live in the entry's scratch block
         CHECK(ensure_scratch(o.slot, wsb + o.count));
         uint8_t* dflags = (uint8_t*)o.slot->scratch + wsb;

@@ -354,7 +354,11 @@ class MontyField:
         """out[0] = sum_i mul(a[i], b[i]) (fpgpu_dot_dev)."""
         return self._fold_dev(self._lib.fpgpu_dot_dev, [a, b], a.numel() // self.n64, out, workspace)
 
-    def inv_workspace_bytes(self, n):
+    def inv_workspace_bytes(self, n, fast=False):
+        """Device scratch of the batch inversion: the minimum, or (fast) the size that also holds the level-0
+        prefixes as limbs -- the call picks its path by the size of the workspace it is given."""
+        if fast:
+            return self._lib.fpgpu_batch_inv_fast_workspace_bytes(self._h, n)
         return self._lib.fpgpu_batch_inv_workspace_bytes(self._h, n)
 
     def inv_dev(self, x, out, flags, workspace):

@@ -85,6 +85,7 @@ extern "C" {
 
     // ---- batch inversion
     pub fn fpgpu_batch_inv_workspace_bytes(ctx: *const fpgpu_ctx, n: usize) -> usize;
+    pub fn fpgpu_batch_inv_fast_workspace_bytes(ctx: *const fpgpu_ctx, n: usize) -> usize;
     pub fn fpgpu_batch_inv_dev(ctx: *const fpgpu_ctx, x: *const c_void, out: *mut c_void, zero_flags: *mut u8, n: usize,
                                workspace: *mut c_void, workspace_bytes: usize, stream: *mut c_void) -> c_int;
     pub fn fpgpu_div_dev(ctx: *const fpgpu_ctx, a: *const c_void, b: *const c_void, out: *mut c_void, zero_flags: *mut u8, n: usize,

@@ -808,6 +808,53 @@ def test_batch_inv_multi_level_plans(cpa, name, p, n64, tuning):
         assert flags[5] == 1 and flags[70000] == 1 and flags[139999] == 1 and flags[6] == 0
 
 
+@pytest.mark.parametrize("name,p,n64", [("bls12_381", 0x1A0111EA397FE69A4B1BA7B6434BACD764774B84F38512BF6730D2A0F6B0F6241EABFFFEB153FFFFB9FEFFFFFFFFAAAB, 6),
+                                        ("p384 tight", 2**384 - 317, 6), ("p512 (tight)", 2**512 - 569, 8), ("p448", 2**448 - 2**224 - 1, 7),
+                                        ("secp256k1 (tight)", 2**256 - 2**32 - 977, 4), ("goldilocks", 2**64 - 2**32 + 1, 1),
+                                        ("odd composite 384", 3 * (2**380 - 2**190 + 5) | 1, 6)])
+@pytest.mark.parametrize("fuse", [1, 0])
+@pytest.mark.parametrize("fast_ws", [False, True])
+def test_batch_inv_every_path_of_the_round3_kernels(cpa, tuning, name, p, n64, fuse, fast_ws):
+    """The sweeps multiply in the Montgomery domain of R' = 2^(29 L), a chain starts as its first element (no
+    multiplication by one, no prefix for it), the last stored level rides in the top kernel (k_binv_top_chain, LDS
+    prefixes) unless FPGPU_INV_FUSE_TOP = 0, and with the larger workspace the level-0 prefixes are kept as limbs
+    in 64-element tiles: every combination against the oracle, bit for bit, on tight, roomy and composite moduli,
+    with zeros at the start, inside and at the end of chains, whole chains of zeros, and chains of one element."""
+    import torch
+    from oracle.fp_oracle import Oracle
+    tuning("FPGPU_INV_FUSE_TOP", fuse)
+    tuning("FPGPU_INV_C0", 8)
+    tuning("FPGPU_INV_C", 4)                       # level 0: 8, above it: 4 (fused when fuse = 1)
+    f, o = cpa.MontyField(p, n64), Oracle(p, n64)
+    rnd = random.Random(n64 * 7 + fuse)
+    for n in (1, 7, 8, 9, 4097, 300007):
+        m = (n + 7) // 8                          # chains at level 0: chain c = {c + k m}
+        xs = [rnd.randrange(1, p) for _ in range(n)]
+        for i in range(0, n, 1013):
+            xs[i] = 0
+        xs[0] = 0                                 # the first element of chain 0
+        if 4 * m + 1 < n:
+            xs[4 * m + 1] = 0                     # inside chain 1
+            for k in range(0, n - 3, m):          # chain 3: nothing but zeros
+                xs[k + 3] = 0
+        xs[-1] = 0
+        if "composite" in name and n > 1000:
+            xs[5], xs[n // 2] = 3, 9
+        x = ints_to_array(xs, n64)
+        want, wflags = o.batch_inv(x)
+        dx = torch.from_numpy(x.view(np.int64)).cuda()
+        out = f.alloc(n)
+        flags = torch.empty(n, dtype=torch.uint8, device="cuda")
+        ws = torch.empty(f.inv_workspace_bytes(n, fast=fast_ws), dtype=torch.uint8, device="cuda")
+        f.inv_dev(dx, out, flags, ws)
+        torch.cuda.synchronize()
+        assert np.array_equal(flags.cpu().numpy(), wflags), (n, "flags")
+        assert np.array_equal(out.cpu().numpy().view(np.uint64), want), n
+    assert f.inv_workspace_bytes(1 << 20, fast=True) >= f.inv_workspace_bytes(1 << 20)
+    if n64 >= 6:
+        assert f.inv_workspace_bytes(1 << 20, fast=True) > f.inv_workspace_bytes(1 << 20) + (1 << 20) * 8 * n64
+
+
 def test_device_wrappers_validate_shapes(cpa):
     """The Python device wrappers refuse operands whose element counts do not match what the kernel
     will touch (a short `out` would otherwise be written past its end)."""
