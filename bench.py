@@ -326,7 +326,8 @@ def bench_batch_inv(args, world, rank, time_steps, primary, samples):
     x = fq.random_dev(n, 0xB15 ^ (7 + 1000 * rank))
     out = fq.alloc(n)
     flags = torch.empty(n, dtype=torch.uint8, device="cuda")
-    ws = torch.empty(fq.inv_workspace_bytes(n), dtype=torch.uint8, device="cuda")
+    # the larger of the two workspace sizes: level-0 prefixes stay in the multiplier's limb form (include/fpgpu.h)
+    ws = torch.empty(fq.inv_workspace_bytes(n, fast=True), dtype=torch.uint8, device="cuda")
     steps = args.steps if primary else 5
     wall, kern = time_steps(lambda: fq.inv_dev(x, out, flags, ws), steps, max(1, args.warmup) if primary else 3)
     # property check: x * inv(x) == one wherever x != 0
@@ -338,7 +339,8 @@ def bench_batch_inv(args, world, rank, time_steps, primary, samples):
         idx = torch.arange(0, n, max(1, n // 512), device="cuda")
         samples["batch_inv"] = (x[idx].cpu().numpy().view(np.uint64), out[idx].cpu().numpy().view(np.uint64))
     # 3 Montgomery multiplications per element = 3 x (2*12^2 + 12) = 900 32-bit multiplies
-    # (the kernels execute 3.03 x 406 on 14 unsaturated 29-bit limbs)
+    # (the kernels execute 3 x 31/32 + 0.1 of them per element, 406 multiplies each on 14 unsaturated 29-bit limbs,
+    # DESIGN.md section 4)
     mads = 900.0 * n / kern / 1e12
     res = {"Ginv_per_s": total * steps / wall / 1e9, "ms_per_batch": wall / steps * 1e3,
            "elements_total": total, "bound": "valu", "mads_per_element": 900,
@@ -356,7 +358,7 @@ def bench_batch_inv(args, world, rank, time_steps, primary, samples):
                             "frac": mads / VALU_MAD_PEAK_TOPS, "traffic": traffic, "traffic_source": traffic_src,
                             "traffic_unit": "HBM bytes per batch, all k_binv_* launches (PMC)",
                             "algorithmic_bytes_per_launch": 96 * n, "hbm_frac_of_8TBps": res["hbm_frac"],
-                            "kernel": "k_binv_up / k_binv_top / k_binv_down <12>", "kernel_ms": kern * 1e3},
+                            "kernel": "k_binv_up / k_binv_top_chain / k_binv_down <12>", "kernel_ms": kern * 1e3},
                "verified_vs_oracle": ok}
     return res
 
@@ -517,7 +519,7 @@ def bench_in_library_sharded(devices, steps=5, warmup=2):
         vo = V.DeviceVector.alloc(f, n, V.PLACE_SHARDED)
         dt = timed(lambda: f.mul_vec(va, vb, vo), vo.sync)
         res["mul_bn254"] = {"elements_total": n, "ms": dt * 1e3, "Gmul_per_s": n / dt / 1e9,
-                            "hbm_frac_per_device_entry": 96.0 * n / dt / 1e9 / HBM_PEAK_GBPS / len(set(devices))}
+                            "hbm_frac_per_gpu": 96.0 * n / dt / 1e9 / HBM_PEAK_GBPS / len(set(devices))}
         for v in (va, vb, vo):
             v.free()
 
