@@ -59,6 +59,8 @@ def parse():
                     help="device list of the in-library sharded measurement (extra.in_library_sharded), e.g. 0,0,0,0,0,0,0,0 to "
                          "rehearse eight parts on one GPU; default: 0..N-1")
     ap.add_argument("--no-sharded", action="store_true", help="skip extra.in_library_sharded")
+    ap.add_argument("--sharded-only", action="store_true",
+                    help="measure extra.in_library_sharded alone and print it as one JSON object (how the main run obtains it)")
     return ap.parse_args()
 
 
@@ -96,6 +98,10 @@ def self_launch(args):
 
 def main():
     args = parse()
+    if args.sharded_only:
+        devs = [int(t) for t in args.sharded_devices.split(",")] if args.sharded_devices else list(range(args.gpus))
+        print(json.dumps({"in_library_sharded": bench_in_library_sharded(devs)}), flush=True)
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args))
     import numpy as np
@@ -166,6 +172,7 @@ def main():
 
     result = {}
     extra = {}
+    distributed_done = False
     samples = {}   # small host copies of GPU results; checked against the oracle in the CPU leg only
 
     # ---------------- primary workload ------------------------------------------------
@@ -261,19 +268,20 @@ def main():
     # ---------------- one process, every GPU, inside the C ABI ----------
     # The survey's own multi-GPU design: ONE process names the devices (fpgpu_set_devices), its vectors are
     # sharded / replicated handles, one host thread enqueues on every device's stream and RCCL
-    # (ncclCommInitAll) gathers the mat-vec's row blocks.  Rank 0 drives all `world` GPUs once every rank has
-    # released its memory; a failure here is reported in the block, it never costs the bench line.
+    # (ncclCommInitAll) gathers the mat-vec's row blocks.  Rank 0 starts it as a CHILD process (bench.py
+    # --sharded-only, a time limit on it) once every rank has released its memory: the first contact with several
+    # physical GPUs happens on the driver's node, and neither a failure nor a hang there may cost the bench line.
     if not args.no_extra and not args.no_sharded:
         a = b = out = None
         ops.clear()
         torch.cuda.empty_cache()
         barrier()
+        if distributed:   # the last collective is behind us: the other ranks may go while rank 0 measures on
+            dist.destroy_process_group()
+            distributed_done = True
         if rank == 0:
             devs = [int(t) for t in args.sharded_devices.split(",")] if args.sharded_devices else list(range(world))
-            try:
-                extra["in_library_sharded"] = bench_in_library_sharded(devs)
-            except Exception as exc:   # noqa: BLE001 - first contact with several physical GPUs happens on the driver's node
-                extra["in_library_sharded"] = {"devices": devs, "error": "%s: %s" % (type(exc).__name__, exc)}
+            extra["in_library_sharded"] = run_in_library_sharded(devs)
 
     # ---------------- CPU baseline (rank 0, N = 1 only) --------------------------------
     cpu = None
@@ -310,7 +318,7 @@ def main():
             "extra": extra,
         }
         print(json.dumps(line), flush=True)
-    if distributed:
+    if distributed and not distributed_done:
         dist.destroy_process_group()
 
 
@@ -481,6 +489,22 @@ def bench_matvec(args, f, world, rank, distributed, time_steps, primary, samples
                             "kernel": "k_matvec_mfma<8,4> (+ k_mv_expand, k_mv_finish)"},
                "verified_vs_oracle": None}
     return res
+
+
+def run_in_library_sharded(devices, limit_s=300):
+    """bench.py --sharded-only as a child process: its one JSON object, or what went wrong."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--sharded-only", "--sharded-devices", ",".join(str(d) for d in devices)]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK",
+                                                            "TORCHELASTIC_RUN_ID", "MASTER_ADDR", "MASTER_PORT")}
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=limit_s, env=env)
+    except subprocess.TimeoutExpired:
+        return {"devices": list(devices), "error": "no result within %d s (child process killed)" % limit_s}
+    for ln in reversed(r.stdout.splitlines()):
+        if ln.startswith("{") and "in_library_sharded" in ln:
+            return json.loads(ln)["in_library_sharded"]
+    return {"devices": list(devices), "error": "child exited with %d: %s" % (r.returncode, (r.stderr or r.stdout)[-400:])}
 
 
 def bench_in_library_sharded(devices, steps=5, warmup=2):
