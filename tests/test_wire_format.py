@@ -9,7 +9,11 @@ those encodings back to back.  The C ABI takes n64 little-endian u64 words per e
 back -- on this little-endian host the same bytes, so a received buffer can be handed to the
 library as it lies and a result buffer can be sent as it lies.  Checked for the three adapters'
 widths: MontyField n64 = 1 (Goldilocks), ConstMontyField n64 = 4 (BN254 Fr), BoxedMontyField
-n64 = 6 (BLS12-381 Fq at 384-bit precision)."""
+n64 = 6 (BLS12-381 Fq at 384-bit precision).
+
+PARITY UNPINNED: the expectation below is a restatement (Python's int.to_bytes(..., "little")) of what
+crypto-bigint's serialiser is understood to write; the reference holds no byte fixture of a serialised
+element and crypto-bigint is not in its tree, so this is not a check against the reference itself."""
 import sys
 
 import numpy as np
