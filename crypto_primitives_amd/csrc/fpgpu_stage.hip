@@ -310,11 +310,17 @@ int run_lanes(const LaneSet& set, Body&& body) {
     LaneStatus st;
     Join join;
     join.pending = T - 1;
-    for (int t = 1; t < T; t++)
-        g_stage.pool->submit([&, t] {
+    for (int t = 1; t < T; t++) {
+        try {
+            g_stage.pool->submit([&, t] {
+                st.note(body(t));
+                join.done();
+            });
+        } catch (const std::exception&) {   // no memory for the task: this thread does the lane's share itself
             st.note(body(t));
             join.done();
-        });
+        }
+    }
     st.note(body(0));
     join.wait();
     return st.result();
@@ -454,7 +460,15 @@ int prepare(const LaneSet& set, const CopySeg* segs, size_t count, bool up, std:
     return FPGPU_OK;
 }
 
-int staged_multi(const CopySeg* segs, size_t count, bool up) {
+int staged_multi_impl(const CopySeg* segs, size_t count, bool up);
+int staged_multi(const CopySeg* segs, size_t count, bool up) {   // nothing may unwind through the C ABI
+    try {
+        return staged_multi_impl(segs, count, up);
+    } catch (const std::exception&) {
+        return fail(FPGPU_ERR_HIP, "out of host memory in a staged transfer");
+    }
+}
+int staged_multi_impl(const CopySeg* segs, size_t count, bool up) {
     size_t total = 0;
     std::vector<int> distinct;
     for (size_t i = 0; i < count; i++) {
@@ -622,7 +636,15 @@ bool host_stream_usable(size_t bytes) {
 // The chunk pipeline for any per-element map of host arrays (see StreamJob): returns FPGPU_ERR_UNSUPPORTED
 // without touching anything when the lanes cannot be had -- the caller then takes its whole-operand path.
 // (A device that cannot hold a lane's slots -- out of memory -- only costs THIS call the pipeline.)
-int host_stream_map(const StreamJob& job) {
+static int host_stream_map_impl(const StreamJob& job);
+int host_stream_map(const StreamJob& job) {   // nothing may unwind through the C ABI
+    try {
+        return host_stream_map_impl(job);
+    } catch (const std::exception&) {
+        return fail(FPGPU_ERR_HIP, "out of host memory in the chunk pipeline");
+    }
+}
+static int host_stream_map_impl(const StreamJob& job) {
     if (job.n == 0) return FPGPU_OK;
     const int want = lanes_wanted();
     if (want == 1) return FPGPU_ERR_UNSUPPORTED;

@@ -699,6 +699,7 @@ static int vec_upload_bytes(fpgpu_vec* v, const char* host, size_t first, size_t
     // every part that overlaps the range (every copy of a replicated vector), all devices in flight together:
     // each part's copies are ordered behind what its stream holds, and the data is in device memory on return
     std::vector<CopySeg> segs;
+    segs.reserve(v->parts.size());   // (std::bad_alloc here would be the process's last gasp anyway; the transfer itself catches)
     for (VecPart& p : v->parts) {
         const size_t lo = std::max(first, p.first), hi = std::min(first + n, p.first + p.count);
         if (lo >= hi) continue;
