@@ -519,10 +519,16 @@ class MontyField {
     }
 
     // --- BATCH extension on device-resident vectors (fpgpu_vec): no host copy between calls -------
-    DeviceVec alloc_device(size_t n, Placement where = Placement::Current) const { return DeviceVec(ctx_.get(), n, where); }
-    DeviceVec alloc_device_rows(size_t rows, size_t cols, Placement where) const { return DeviceVec(ctx_.get(), rows * cols, where, cols); }
-    DeviceVec to_device(const std::vector<Element>& v, Placement where = Placement::Current, size_t row_len = 0) const {
-        DeviceVec d(ctx_.get(), v.size(), where, row_len);
+    // (`on`: a DeviceSet to lay the vector out over instead of the process-wide list of set_devices)
+    DeviceVec alloc_device(size_t n, Placement where = Placement::Current, const DeviceSet* on = nullptr) const {
+        return DeviceVec(ctx_.get(), n, where, 0, on);
+    }
+    DeviceVec alloc_device_rows(size_t rows, size_t cols, Placement where, const DeviceSet* on = nullptr) const {
+        return DeviceVec(ctx_.get(), rows * cols, where, cols, on);
+    }
+    DeviceVec to_device(const std::vector<Element>& v, Placement where = Placement::Current, size_t row_len = 0,
+                        const DeviceSet* on = nullptr) const {
+        DeviceVec d(ctx_.get(), v.size(), where, row_len, on);
         if (!v.empty()) d.upload(p(v.data()), 0, v.size());
         return d;
     }

@@ -106,6 +106,30 @@ static void gpu_part(void)
     CHECK(fpgpu_vec_mul(ctx, va, vb, va) == FPGPU_OK);                       /* in place is fine for elementwise */
     CHECK(fpgpu_vec_div(ctx, va, vb, va, NULL, NULL) == FPGPU_ERR_SHAPE);     /* but not for a division */
     fpgpu_vec_free(va); fpgpu_vec_free(vb); fpgpu_vec_free(vt); fpgpu_vec_free(vu);
+    /* a device list as a handle (the process-wide list stays unset): two entries on GPU 0, sharded operands, and the
+     * inversion's two workspace sizes through the *_dev call on one part */
+    {
+        fpgpu_devset *set = NULL;
+        int ids[2] = {0, 0}, got[2] = {-1, -1}, dev = -1;
+        size_t first = 0, count = 0;
+        void *ptr = NULL, *stream = NULL;
+        CHECK(fpgpu_devset_create(ids, 2, &set) == FPGPU_OK && fpgpu_devset_devices(set, got, 2) == 2 && got[0] == 0 && got[1] == 0);
+        CHECK(fpgpu_get_devices(NULL, 0) == 0);
+        CHECK(fpgpu_vec_alloc_on(ctx, set, N, FPGPU_PLACE_SHARDED, &va) == FPGPU_OK && fpgpu_vec_parts(va) == 2);
+        CHECK(fpgpu_vec_alloc_on(ctx, set, N, FPGPU_PLACE_SHARDED, &vb) == FPGPU_OK);
+        CHECK(fpgpu_vec_alloc_on(ctx, set, N, FPGPU_PLACE_SHARDED, &vt) == FPGPU_OK);
+        fpgpu_devset_destroy(set);                                            /* the vectors keep their list */
+        CHECK(fpgpu_vec_upload(va, a, 0, N) == FPGPU_OK && fpgpu_vec_upload(vb, b, 0, N) == FPGPU_OK);
+        CHECK(fpgpu_vec_batch_inv(ctx, vb, vt, flags, &none) == FPGPU_OK && none == 1 && flags[5] == 1);
+        CHECK(fpgpu_vec_mul(ctx, vt, vb, vt) == FPGPU_OK && fpgpu_vec_download(vt, u, 0, N) == FPGPU_OK);
+        same = 1;
+        for (i = 0; i < N; i++)
+            if (i != 5) same = same && memcmp(u + 4 * i, one, 32) == 0;
+        CHECK(same);
+        CHECK(fpgpu_vec_part(va, 1, &dev, &first, &count, &ptr, &stream) == FPGPU_OK && dev == 0 && first + count == N && ptr != NULL);
+        CHECK(fpgpu_batch_inv_fast_workspace_bytes(ctx, N) >= fpgpu_batch_inv_workspace_bytes(ctx, N));
+        fpgpu_vec_free(va); fpgpu_vec_free(vb); fpgpu_vec_free(vt);
+    }
     fpgpu_ctx_destroy(ctx);
     free(a); free(b); free(t); free(u); free(flags);
 }

@@ -322,6 +322,21 @@ static void test_gpu_device_vectors() {
         CHECK(f.from_device(dys) == f.spmv(S, x));
     }
     set_devices({});
+    {   // a device list as a value: vectors laid out over it do not depend on the process-wide list
+        DeviceSet two({0, 0});
+        const size_t n = 5000;
+        std::vector<F::Element> a, b;
+        for (uint64_t i = 0; i < n; i++) { a.push_back(f.project((uint64_t)(i * 0x9E3779B97F4A7C15ull + 1))); b.push_back(f.project((uint64_t)(i * i + 7))); }
+        DeviceVec da = f.to_device(a, Placement::Sharded, 0, &two), db = f.to_device(b, Placement::Sharded, 0, &two);
+        DeviceVec t = f.alloc_device(n, Placement::Sharded, &two);
+        CHECK(da.parts() == 2);
+        f.on_device().mul(da, db, t);
+        f.on_device().add(t, da, t);
+        auto got = f.from_device(t);
+        size_t bad = 0;
+        for (size_t i = 0; i < n; i++) bad += !(got[i] == f.add(f.mul(a[i], b[i]), a[i]));
+        CHECK(bad == 0);
+    }
     // BoxedMontyField: limbs gathered once, chain on the device, scattered once
     auto bf = BoxedMontyField::new_({0xB9FEFFFFFFFFAAABull, 0x1EABFFFEB153FFFFull, 0x6730D2A0F6B0F624ull, 0x64774B84F38512BFull,
                                      0x4B1BA7B6434BACD7ull, 0x1A0111EA397FE69Aull});
