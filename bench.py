@@ -357,7 +357,9 @@ def bench_batch_inv(args, world, rank, time_steps, primary, samples):
            "elements_total": total, "bound": "valu", "mads_per_element": 900,
            "valu_mad_Tops_per_gpu": mads, "valu_frac": mads / VALU_MAD_PEAK_TOPS,
            "algorithmic_GBps_per_gpu": 96 * n / kern / 1e9, "hbm_frac": 96 * n / kern / 1e9 / HBM_PEAK_GBPS,
-           "x_times_inv_is_one": ok}
+           "x_times_inv_is_one": ok,
+           "workspace": "fpgpu_batch_inv_fast_workspace_bytes (level-0 prefixes as limbs): %d bytes; minimum %d" % (
+               fq.inv_workspace_bytes(n, fast=True), fq.inv_workspace_bytes(n))}
     if primary:
         traffic, traffic_src = _pmc_traffic("batch_inv", "elements", n)
         res = {"metric": "BLS12-381 Fq batch inversion Ginv/s", "value": res["Ginv_per_s"], "unit": "Ginv/s",
