@@ -496,7 +496,7 @@ __global__ __launch_bounds__(kBlock) void k_binv_down(const uint32_t* __restrict
 // per SIMD), so every lane's work is pure latency either way; this takes two launches and two HBM round
 // trips of latency out of it.  Zero totals are not skipped here (composite moduli: they poison the group).
 constexpr int kTopChainBlock = 64;   // one wave per workgroup: (C - 1) * RAW * 256 bytes of LDS each, four workgroups per CU
-constexpr int kTopChainMaxC = 8;
+constexpr int kTopChainMaxC = kInvTopChainMaxC;   // fp_launch.hpp: the plan fuses a level only up to this chain length
 template <int N>
 __global__ __launch_bounds__(kTopChainBlock) void k_binv_top_chain(const uint32_t* __restrict__ x, uint32_t* __restrict__ out,
                                                            uint8_t* __restrict__ poisoned,

@@ -37,6 +37,7 @@ constexpr size_t kInvTop = 65536; // stop recursing when this few totals remain:
                                   // pure latency up to one wave per SIMD (2^13 lanes 91 us, 2^16 lanes 103 us on
                                   // 2^24 BLS12-381 elements), a tree level costs 45 us
 constexpr int kInvMaxLevels = 16;
+constexpr int kInvTopChainMaxC = 8;   // longest chain of the last stored level that rides in the top kernel (k_binv_top_chain's LDS is sized by it)
 struct InvPlan {
     int levels = 0;                         // number of up-sweeps
     size_t count[kInvMaxLevels + 1] = {0};  // count[0] = n, count[l+1] = chains at level l

@@ -161,7 +161,7 @@ InvPlan make_inv_plan(uint32_t n64, size_t n) {
     p.bytes = off;
     // the last stored level rides in the top kernel when its chains are short (then that level's own prefix
     // array O_l is still what the level below reads its inverted totals from; X_(l+1) goes unused)
-    p.fused_top = p.levels >= 2 && p.c[p.levels - 1] <= 8;
+    p.fused_top = p.levels >= 2 && p.c[p.levels - 1] <= kInvTopChainMaxC;
     // level-0 prefixes as 29-bit limbs, 4 * STRIDE bytes each (fp_kernels.cuh RawForm).  Measured (tools/exp_binv_ab.py,
     // 2^24 elements): it pays from 384 bits on (BLS12-381 1.065 -> 1.047 ms, 512 bits 1.62 -> 1.57), where the limb form
     // is 12-17 % larger than the words; at 256 bits it is 25 % larger and loses (0.618 -> 0.638 ms)

@@ -186,6 +186,7 @@ struct LaneSet {
 // transfers waiting beside it.  FPGPU_ERR_UNSUPPORTED: staging is not available in this process (no pinned
 // memory) -- the caller takes the plain path.
 int acquire_lanes(int want, LaneSet* out) {
+    out->lanes.reserve(kMaxLanes);   // before any lane is marked busy: a failed allocation must not strand one
     std::unique_lock<std::mutex> l(g_stage.mu);
     if (!g_stage.pool) g_stage.pool = new (std::nothrow) TaskPool();
     if (!g_stage.pool) return FPGPU_ERR_UNSUPPORTED;
