@@ -398,7 +398,7 @@ def test_handle_api_from_several_host_threads(cpa):
             h = big.download()
             back = V.from_host(f, h)
             dot = f.dot_vec(big, back)
-            host = f.mul(h, h)                          # chunk pipeline, also under the staging mutex
+            host = f.mul(h, h)                          # chunk pipeline: every thread on its own staging lanes
             results[t] = (a.download(), b.download(), u.download(), w.download(), s, flags, h, dot, host)
         except Exception as e:                          # noqa: BLE001 - reported below
             errors.append((t, repr(e)))
