@@ -48,16 +48,20 @@ __global__ __launch_bounds__(NT * 64) void k_mv_expand(const uint32_t* __restric
                                                        uint32_t* __restrict__ flag, const FpParams<N> P) {
     constexpr int EB = 4 * N;
     constexpr int MAXEL = 64 * kMV_EXPAND_BATCH / EB + 2;  // elements a batch of k-steps can touch
-    __shared__ int8_t xd[MAXEL][EB];
+    // digits of the batch's elements, EB zero bytes on either side of each: B[k][d] = xd[c][d - s] for k = c EB + s is
+    // then a plain (reversed) window of the row, zero where d - s leaves [0, EB)
+    constexpr int ROW = 3 * EB;
+    __shared__ __attribute__((aligned(16))) int8_t xd[MAXEL][ROW];
     const int nt = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15;
     const int d = 16 * nt + n;
     long long csum = 0;
+    for (int i = threadIdx.x; i < MAXEL * ROW / 4; i += NT * 64) reinterpret_cast<uint32_t*>(&xd[0][0])[i] = 0;   // the padding stays zero
     // A workgroup takes kMV_EXPAND_BATCH consecutive k-steps at a time: their elements are digitised
     // into LDS together (two barriers per batch, not per k-step), then every wave writes its column
     // tile's fragment of each k-step.
     for (size_t ks0 = (size_t)blockIdx.x * kMV_EXPAND_BATCH; ks0 < ksteps; ks0 += (size_t)gridDim.x * kMV_EXPAND_BATCH) {
         const size_t c_first = (64 * ks0) / EB;
-        __syncthreads();  // previous batch's readers are done
+        __syncthreads();  // previous batch's readers are done (and, the first time, the zero fill)
         for (int e = threadIdx.x; e < MAXEL; e += NT * 64) {
             const size_t c = c_first + e;
             uint32_t w[N];
@@ -83,32 +87,51 @@ __global__ __launch_bounds__(NT * 64) void k_mv_expand(const uint32_t* __restric
             }
             unsigned cy = 0;
 #pragma unroll
-            for (int l = 0; l < N; l++) {
-                const uint32_t u = __builtin_addc(w[l], 0x80808080u, cy, &cy) ^ 0x80808080u;
-                xd[e][4 * l + 0] = (int8_t)(u & 0xff);
-                xd[e][4 * l + 1] = (int8_t)((u >> 8) & 0xff);
-                xd[e][4 * l + 2] = (int8_t)((u >> 16) & 0xff);
-                xd[e][4 * l + 3] = (int8_t)(u >> 24);
-            }
+            for (int l = 0; l < N; l++)   // balanced digits, four to a word (little-endian: digit 4l + b is byte b)
+                reinterpret_cast<uint32_t*>(&xd[e][EB])[l] = __builtin_addc(w[l], 0x80808080u, cy, &cy) ^ 0x80808080u;
         }
         __syncthreads();
         const size_t ks_end = ks0 + kMV_EXPAND_BATCH < ksteps ? ks0 + kMV_EXPAND_BATCH : ksteps;
         for (size_t ks = ks0; ks < ks_end; ks++) {
             uint32_t wds[4];
+            if constexpr (EB % 16 == 0) {
+                // the lane's 16 values of k lie in ONE element (16 | EB): bytes j = 0..15 are xd[c][p0 - j], the 16-byte
+                // window of the padded row that ends at p0 = d - s0, reversed.  Five aligned words, a funnel shift, a byte swap.
+                const size_t k0 = 64 * ks + 16 * g;
+                const size_t c = k0 / EB;
+                const int p0 = d - (int)(k0 % EB);
+                const int w0 = EB + p0 - 15;                 // first byte of the window in the row: 1 .. 3 EB - 16
+                const uint32_t* row = reinterpret_cast<const uint32_t*>(&xd[c - c_first][0]) + (w0 >> 2);
+                uint32_t q[5];
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                uint32_t word = 0;
+                for (int i = 0; i < 5; i++) q[i] = row[i < 4 || (w0 & 3) ? i : 3];   // (the fifth word only exists off alignment)
+                const uint32_t sh = (uint32_t)(w0 & 3);
 #pragma unroll
-                for (int b = 0; b < 4; b++) {
-                    const size_t k = 64 * ks + 16 * g + 4 * q + b;
-                    const size_t c = k / EB;   // c - c_first <= 64 * kMV_EXPAND_BATCH / EB < MAXEL
-                    const int s = (int)(k % EB), t = d - s;
-                    int v = 0;
-                    if (c < cols && t >= 0 && t < EB) v = xd[c - c_first][t];
-                    csum += v;
-                    word |= (uint32_t)(v & 0xff) << (8 * b);
+                for (int i = 0; i < 4; i++) {
+                    const uint32_t win = __builtin_amdgcn_alignbyte(q[i + 1], q[i], sh);   // window bytes 4i .. 4i + 3
+                    wds[3 - i] = __builtin_bswap32(win);
+                    csum += __builtin_amdgcn_sdot4((int)win, 0x01010101, 0, false);
                 }
-                wds[q] = word;
+                if (c >= cols) {   // k past the last column: B is zero there (the rows of xd beyond cols are zero already)
+#pragma unroll
+                    for (int i = 0; i < 4; i++) wds[i] = 0;
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    uint32_t word = 0;
+#pragma unroll
+                    for (int b = 0; b < 4; b++) {
+                        const size_t k = 64 * ks + 16 * g + 4 * q + b;
+                        const size_t c = k / EB;   // c - c_first <= 64 * kMV_EXPAND_BATCH / EB < MAXEL
+                        const int s = (int)(k % EB), t = d - s;
+                        int v = 0;
+                        if (c < cols && t >= 0 && t < EB) v = xd[c - c_first][EB + t];
+                        csum += v;
+                        word |= (uint32_t)(v & 0xff) << (8 * b);
+                    }
+                    wds[q] = word;
+                }
             }
             *reinterpret_cast<uint4*>(Bw + (ks * NT + nt) * 1024 + lane * 16) = make_uint4(wds[0], wds[1], wds[2], wds[3]);
         }
