@@ -29,3 +29,18 @@ def test_host_mirror_batch_api_on_gpu():
     r = subprocess.run([EXE, "gpu"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "0 failures" in r.stdout
+
+
+STRESS = os.path.join(ROOT, "tests", "cpp", "stress_host_layers")
+
+
+@pytest.mark.gpu
+def test_host_layers_under_sixteen_threads():
+    """tests/cpp/stress_host_layers.cpp: sixteen host threads of host-buffer calls, vectors sharded over device sets that
+    name GPU 0 three and five times, partial transfers across part boundaries, gathered and row-sharded matrix products,
+    sparse products and inversions on handles, device sets destroyed under live vectors -- every sharded result against
+    the one-device call.  (tools/build_san.sh builds the same driver against an AddressSanitizer build of the host layers.)"""
+    assert os.path.exists(STRESS), "tests/cpp/stress_host_layers must be prebuilt (__graft_entry__.build())"
+    r = subprocess.run([STRESS, "16", "2"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "0 failures" in r.stdout
