@@ -151,7 +151,7 @@ hipError_t Launch<N>::matvec(const fpgpu_ctx* ctx, const void* A, size_t rows, s
             unsigned long long* Dbuf = (unsigned long long*)(ws + pl.d_off);
             uint8_t* Bw = ws + pl.b_off;
             if (hipError_t e = hipMemsetAsync(ws, 0, pl.b_off, s); e != hipSuccess) return e;
-            const size_t ksteps = (size_t)pl.chunks_total * 8;
+            const size_t ksteps = (size_t)pl.chunks_total * mv_chunk_ksteps(NT);
             const size_t ebatches = (ksteps + kMV_EXPAND_BATCH - 1) / kMV_EXPAND_BATCH;
             const unsigned eg = (unsigned)(ebatches < 512 ? ebatches : 512);
             hipLaunchKernelGGL((k_mv_expand<N, NT>), dim3(eg), dim3(NT * 64), 0, s, (const uint32_t*)x, cols, ksteps, Bw,
@@ -183,6 +183,17 @@ hipError_t Launch<N>::matvec(const fpgpu_ctx* ctx, const void* A, size_t rows, s
     const uint32_t* Ap = (const uint32_t*)A;
     const uint32_t* xp = (const uint32_t*)x;
     uint32_t* yp = (uint32_t*)y;
+    // Which VALU kernel: k_matvec_cols (unsaturated column sums, one row per wave) from 192 to 384 bits, where it is
+    // ahead (8 GiB matrices, TB/s of matrix bytes, k_matvec / k_matvec_cols: 192 bits 4.88 / 4.95, BN254 4.80 / 5.33,
+    // 320 bits 4.20 / 4.14, BLS12-381 3.78 / 4.09; 448 bits 3.44 / 3.19 and 512 bits 3.16 / 3.12 with 256 registers
+    // and one wave per SIMD; one and two words 4.69 / 4.66 and 5.37 / 5.39).  FPGPU_MATVEC_COLS forces either.
+    const bool cols_kernel = tune.matvec_cols >= 0 ? tune.matvec_cols == 1 : (N >= 6 && N <= 12);
+    if (cols_kernel && t_env <= 1) {
+        const size_t wgs = (rows + kBlock / 64 - 1) / (kBlock / 64);
+        const int g2 = (int)(wgs < grid_cap ? (wgs ? wgs : 1) : grid_cap);
+        hipLaunchKernelGGL((k_matvec_cols<N>), dim3(g2), dim3(kBlock), 0, s, Ap, xp, yp, rows, cols, gate, make_params<N>(ctx));
+        return hipSuccess;
+    }
     if (T >= 4)
         hipLaunchKernelGGL((k_matvec<N, 4>), dim3(grid), dim3(kBlock), 0, s, Ap, xp, yp, rows, cols, gate, make_params<N>(ctx));
     else if (T >= 2)

@@ -679,6 +679,93 @@ __global__ __launch_bounds__(kBlock) void k_matvec(const uint32_t* __restrict__ 
     }
 }
 
+// ---- dense mat-vec on unsaturated limbs: carry-free column sums carried ACROSS terms ----------------
+// The same sum as k_matvec, computed as k_matmul computes its terms (fp_unsat.cuh, 29-bit limbs): a term a*b is L^2
+// v_mad_u64_u32 into 2L - 1 independent 64-bit column sums that live across the terms of a row -- no carry
+// instruction, no per-term reduction -- normalised every floor(63 / L) terms.  One row per WAVE: lane t takes
+// columns t, t + 64, ... (a wave-load of A is 64 consecutive elements), the next element's loads are issued before
+// the current element's multiplies, the 64 lanes' column sums are added with shuffles (plain integers: no modular
+// step), and the exact integer V = sum of a*b is rebuilt and reduced once per row as in k_matmul:
+// V = W0 + W1 R + W2 R^2  =>  V R^-1 = mont(W0, 1) + mont(W1, R) + mont(W2, R^2)  (mod p), the canonical residue,
+// i.e. the reference's fold of mul and add, for any a, b < R and any number of columns below 2^32.
+// Against k_matvec (N^2 multiply-adds + N^2 carry adds + a wide add per term): 81 + ~45 instead of ~160 instructions
+// per 256-bit term, 196 + ~100 instead of ~330 per 384-bit term -- the wide fields stop being VALU-bound.
+template <int N>
+__global__ __launch_bounds__(kBlock) void k_matvec_cols(const uint32_t* __restrict__ A, const uint32_t* __restrict__ x,
+                                                        uint32_t* __restrict__ y, size_t rows, size_t cols,
+                                                        const uint32_t* __restrict__ run_if_set, const FpParams<N> P) {
+    constexpr int L = UF<N>::L, NC = 2 * L + 2, TT = 63 / L;   // TT * L products of < 2^58 and a carry fit 64 bits
+    constexpr uint32_t M = UF<N>::C::MASK;
+    if (run_if_set && *run_if_set == 0) return;
+    const int lane = threadIdx.x & 63;
+    const size_t waves = (size_t)gridDim.x * (kBlock / 64);
+    for (size_t row = (size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); row < rows; row += waves) {
+        const uint32_t* __restrict__ Arow = A + row * cols * N;
+        uint64_t c[NC];
+#pragma unroll
+        for (int i = 0; i < NC; i++) c[i] = 0;
+        auto normalise = [&]() {
+#pragma unroll
+            for (int i = 0; i + 1 < NC; i++) {
+                c[i + 1] += c[i] >> kUB;
+                c[i] &= M;
+            }
+        };
+        uint32_t va[N], vx[N];
+        size_t j = lane;
+        bool have = j < cols;
+        if (have) {
+            load_elem<N>(va, Arow, j);
+            load_elem<N>(vx, x, j);
+        }
+        int pending = 0;
+        while (have) {
+            uint32_t a[L], b[L];
+            uload<N>(a, va);
+            uload<N>(b, vx);
+            const size_t jn = j + 64;
+            const bool hn = jn < cols;
+            if (hn) {   // in flight over this element's multiplies
+                load_elem<N>(va, Arow, jn);
+                load_elem<N>(vx, x, jn);
+            }
+#pragma unroll
+            for (int i = 0; i < L; i++)
+#pragma unroll
+                for (int k = 0; k < L; k++) c[i + k] += (uint64_t)a[i] * b[k];
+            if (++pending == TT) {
+                normalise();
+                pending = 0;
+            }
+            j = jn;
+            have = hn;
+        }
+        normalise();   // every column below 2^29 (the top one holds what was carried out: small)
+        // 64 lanes x < 2^30 per column: the wave's sums stay far below 2^64
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1)
+#pragma unroll
+            for (int i = 0; i < NC; i++) c[i] += __shfl_down((unsigned long long)c[i], off, 64);
+        normalise();
+        normalise();
+        uint32_t limbs[NC], w[3 * N];
+#pragma unroll
+        for (int i = 0; i < NC; i++) limbs[i] = (uint32_t)c[i];
+        from_limbs<3 * N, kUB, NC>(w, limbs);   // V < cols * R^2 < 2^(64 N + 32): words beyond that are zero
+        uint32_t w0[N], w1[N], w2[N], one[N], r1[N], r2[N], t0[N], t1[N], t2[N], s[N], acc[N];
+#pragma unroll
+        for (int l = 0; l < N; l++) { w0[l] = w[l]; w1[l] = w[N + l]; w2[l] = w[2 * N + l]; one[l] = l == 0 ? 1u : 0u; }
+        set_limbs<N>(r1, P.one);
+        set_limbs<N>(r2, P.r2);
+        mont_mul<N>(t0, w0, one, P);
+        mont_mul<N>(t1, w1, r1, P);
+        mont_mul<N>(t2, w2, r2, P);
+        mod_add<N>(s, t0, t1, P);
+        mod_add<N>(acc, s, t2, P);
+        if (lane == 0) store_elem<N>(y, row, acc);
+    }
+}
+
 // ---- sparse mat-vec over SparseMatrix<T> (src/matrix.rs:46-61: `density`
 // cells (column index, value) per row, rows stored back to back) -----------------------
 // y[i] = sum_{j < density} mul(val[i*density + j], x[col[i*density + j]]): the same fold of mul and

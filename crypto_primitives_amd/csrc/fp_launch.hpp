@@ -58,6 +58,8 @@ InvPlan make_inv_plan(uint32_t n64, size_t n);
 #define FPGPU_MV_WAVES 8
 #endif
 constexpr int kMV_WAVES = FPGPU_MV_WAVES;  // waves per workgroup of k_matvec_mfma: 16 rows each
+// k-steps (64 bytes of every row) per staged chunk of the Toeplitz operand, by n64 (see k_matvec_mfma)
+constexpr int mv_chunk_ksteps(uint32_t n64) { return n64 <= 4 ? 8 : 4; }
 struct MvPlan {
     bool usable;
     uint32_t nt, rowblocks, ksplit, chunks_total;
@@ -74,14 +76,30 @@ inline MvPlan make_mv_plan(uint32_t n64, size_t rows, size_t cols) {
     pl.nt = n64;  // ceil((2 EB - 1) / 16)
     pl.rowblocks = (uint32_t)((rows + kMV_WAVES * 16 - 1) / (kMV_WAVES * 16));
     const size_t ksteps = (cols * eb + 63) / 64;
-    pl.chunks_total = (uint32_t)((ksteps + 7) / 8);
-    uint32_t ks = (256 + pl.rowblocks - 1) / pl.rowblocks;  // at least one workgroup per CU; columns split when rows are few
-    if (ks > pl.chunks_total) ks = pl.chunks_total;
-    pl.ksplit = ks < 1 ? 1 : ks;
+    const size_t kc = (size_t)mv_chunk_ksteps(n64);
+    pl.chunks_total = (uint32_t)((ksteps + kc - 1) / kc);
+    // Column parts per row block.  A CU streams this access pattern (64 bytes of each of 16 rows per wave instruction) at
+    // a bounded rate whatever it holds -- tools/ubench_rowtile_stride.hip: 128 workgroups 4.1 TB/s, 340 4.9, 256 or 510
+    // 6.0-6.2 -- so the launch is as fast as its fullest CU: cost(k) = ceil(row blocks * k / 256) / k.  Take the SMALLEST
+    // split within 5 % of the best cost among splits that keep a part at 8 chunks or more and the grid near 3072
+    // workgroups (every part adds a prologue and a round of atomics per row; tools/time_matvec_ksplit.py: 170 row
+    // blocks 3.5 TB/s with 1 or 2 parts, 4.9 with 3; 171: 3.5 with 3, 4.5 with 4 ... 16; 32: 5.3 with 8).
+    uint32_t ks = 1;
+    {
+        uint32_t most = pl.chunks_total / 8;
+        if (most > 256) most = 256;
+        if (const uint32_t by_grid = 3072 / pl.rowblocks; most > by_grid) most = by_grid;
+        if (most < 1) most = 1;
+        auto cost = [&](uint32_t k) { return (double)(((uint64_t)pl.rowblocks * k + 255) / 256) / k; };
+        double best = cost(1);
+        for (uint32_t k = 2; k <= most; k++) best = cost(k) < best ? cost(k) : best;
+        while (ks < most && cost(ks) > 1.05 * best) ks++;
+    }
+    pl.ksplit = ks;
     pl.colsum_off = 256;
     pl.d_off = pl.colsum_off + ((16 * pl.nt * 8 + 255) / 256) * 256;
     pl.b_off = pl.d_off + (((size_t)pl.rowblocks * (kMV_WAVES * 16) * 16 * pl.nt * 8 + 1023) / 1024) * 1024;
-    pl.bytes = pl.b_off + (size_t)pl.chunks_total * 8 * pl.nt * 1024;
+    pl.bytes = pl.b_off + (size_t)pl.chunks_total * kc * pl.nt * 1024;
     return pl;
 }
 // Workspace of the matrix-core mat-mul (fp_matmul_mfma.cuh): a flag word, then the int8 digit
@@ -119,6 +137,7 @@ struct Tuning {
     long matvec_mfma = -1;    // FPGPU_MATVEC_MFMA: 0 forces the VALU mat-vec
     long matvec_ksplit = 0;   // FPGPU_MATVEC_KSPLIT: column parts per row block (matrix-core mat-vec)
     long matvec_t = 0;        // FPGPU_MATVEC_T: products per pass of the VALU mat-vec
+    long matvec_cols = -1;    // FPGPU_MATVEC_COLS: 1 = VALU mat-vec on unsaturated column sums (k_matvec_cols), 0 = k_matvec; -1 = the launcher's choice
     long matmul_mfma = -1;    // FPGPU_MATMUL_MFMA: 0 forces the VALU single-limb mat-mul
     long matmul_generic = 0;  // FPGPU_MATMUL_GENERIC: 1 forces the multi-limb mat-mul kernel
     long spmv_log2g = -1;     // FPGPU_SPMV_LOG2G: log2 of the lanes sharing a sparse row

@@ -34,7 +34,6 @@
 
 namespace fpgpu {
 
-constexpr int kMV_CHUNK = 8;       // k-steps (64 bytes of every row) per staged B chunk
 constexpr int kMV_EXPAND_BATCH = 32;  // k-steps a workgroup of k_mv_expand digitises at a time
 typedef int mv_v4i __attribute__((ext_vector_type(4)));
 
@@ -148,10 +147,13 @@ __global__ __launch_bounds__(kMV_WAVES * 64) void k_matvec_mfma(const uint8_t* _
                                                                 const uint8_t* __restrict__ Bw, uint32_t chunks_total,
                                                                 uint32_t ksplit, unsigned long long* __restrict__ Dbuf,
                                                                 const uint32_t* __restrict__ flag) {
-    constexpr int CHUNK_BYTES = kMV_CHUNK * NT * 1024;
+    // k-steps per staged chunk of B: 8 up to 256 bits; 4 beyond, where two 8-step buffers (16 NT KiB) would leave room
+    // for ONE workgroup per CU (BLS12-381: 96 of 160 KiB) and too few loads in flight to cover HBM's latency
+    constexpr int KC = mv_chunk_ksteps(NT);
+    constexpr int CHUNK_BYTES = KC * NT * 1024;
     // |a - 128| <= 128, |xd| <= 128: a k-step adds at most 64 * 2^14 = 2^20 to a diagonal sum,
-    // so 2047 k-steps are exact in int32; flush every 255 chunks of 8
-    constexpr uint32_t flush_every = 255;
+    // so 2047 k-steps are exact in int32; flush every 2040 k-steps
+    constexpr uint32_t flush_every = 2040 / KC;
     __shared__ __attribute__((aligned(1024))) uint8_t lds[2 * CHUNK_BYTES];
     if (*flag) return;  // x has no EB-digit form: the VALU kernel k_matvec runs instead
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -167,9 +169,9 @@ __global__ __launch_bounds__(kMV_WAVES * 64) void k_matvec_mfma(const uint8_t* _
 
     auto stage = [&](uint32_t c, int buf) {  // chunk c of B -> LDS buffer buf: NT KiB per k-step, 8 KiB per DMA round
 #pragma unroll
-        for (int q = 0; q < (kMV_CHUNK * NT + kMV_WAVES - 1) / kMV_WAVES; q++) {
+        for (int q = 0; q < (KC * NT + kMV_WAVES - 1) / kMV_WAVES; q++) {
             const int piece = q * kMV_WAVES + wave;
-            if ((kMV_CHUNK * NT) % kMV_WAVES != 0 && piece >= kMV_CHUNK * NT) break;
+            if ((KC * NT) % kMV_WAVES != 0 && piece >= KC * NT) break;
             __builtin_amdgcn_global_load_lds(
                 (const __attribute__((address_space(1))) void*)(Bw + (size_t)c * CHUNK_BYTES + piece * 1024 + lane * 16),
                 (__attribute__((address_space(3))) void*)(lds + buf * CHUNK_BYTES + piece * 1024), 16, 0, 0);
@@ -180,17 +182,17 @@ __global__ __launch_bounds__(kMV_WAVES * 64) void k_matvec_mfma(const uint8_t* _
     // draining the chunk that should stay in flight across the barrier.
     // (One address register pair per chunk and immediate offsets.  Only the last chunk of a row can
     // reach past the row's end, where B is zero: those lanes read the row's last 16 bytes instead.)
-    const bool ragged = (size_t)chunks_total * (kMV_CHUNK * 64) > rowbytes;
-    auto load_a = [&](uint32_t c, mv_v4i (&v)[kMV_CHUNK]) {
+    const bool ragged = (size_t)chunks_total * (KC * 64) > rowbytes;
+    auto load_a = [&](uint32_t c, mv_v4i (&v)[KC]) {
         if (!ragged || c + 1 < chunks_total) {
-            const uint8_t* pc = arow + (size_t)c * (kMV_CHUNK * 64) + lane_off;
+            const uint8_t* pc = arow + (size_t)c * (KC * 64) + lane_off;
 #pragma unroll
-            for (int t = 0; t < kMV_CHUNK; t++)
+            for (int t = 0; t < KC; t++)
                 asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(v[t]) : "v"(pc), "n"(t * 64));
         } else {
 #pragma unroll
-            for (int t = 0; t < kMV_CHUNK; t++) {
-                size_t off = ((size_t)c * kMV_CHUNK + t) * 64 + lane_off;
+            for (int t = 0; t < KC; t++) {
+                size_t off = ((size_t)c * KC + t) * 64 + lane_off;
                 off = off < last_off ? off : last_off;
                 asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v[t]) : "v"(arow + off));
             }
@@ -215,18 +217,18 @@ __global__ __launch_bounds__(kMV_WAVES * 64) void k_matvec_mfma(const uint8_t* _
             }
     };
 
-    // Three register sets of 8 x 16 bytes rotate by name (no copies: a register with a load in flight
+    // Three register sets of KC x 16 bytes rotate by name (no copies: a register with a load in flight
     // must not be read): one computes, one was issued a chunk ago, one is issued now.  At the end of a
-    // phase the outstanding memory operations are, oldest first, the previous phase's 8 loads, this
-    // phase's NT DMAs and its 8 loads: vmcnt(8) retires all but the newest 8, i.e. the next operand set
+    // phase the outstanding memory operations are, oldest first, the previous phase's KC loads, this
+    // phase's DMAs and its KC loads: vmcnt(KC) retires all but the newest KC, i.e. the next operand set
     // and the next B chunk, and leaves a whole chunk in flight across the barrier.
-    mv_v4i s0[kMV_CHUNK], s1[kMV_CHUNK], s2[kMV_CHUNK];
+    mv_v4i s0[KC], s1[KC], s2[KC];
     uint32_t since_flush = 0;
     uint32_t c = c0;
-    auto compute = [&](mv_v4i (&cur)[kMV_CHUNK], int buf) {
+    auto compute = [&](mv_v4i (&cur)[KC], int buf) {
         const uint8_t* base = lds + buf * CHUNK_BYTES + lane * 16;
 #pragma unroll
-        for (int t = 0; t < kMV_CHUNK; t++) {
+        for (int t = 0; t < KC; t++) {
             const mv_v4i a = cur[t] ^ (int)0x80808080;  // unsigned bytes -> a - 128 as int8
 #pragma unroll
             for (int nt = 0; nt < NT; nt++) {
@@ -239,11 +241,11 @@ __global__ __launch_bounds__(kMV_WAVES * 64) void k_matvec_mfma(const uint8_t* _
             since_flush = 0;
         }
     };
-    auto retire = [&](mv_v4i (&landed)[kMV_CHUNK]) {
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    auto retire = [&](mv_v4i (&landed)[KC]) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KC) : "memory");
         __builtin_amdgcn_s_barrier();
 #pragma unroll
-        for (int t = 0; t < kMV_CHUNK; t++) asm volatile("" : "+v"(landed[t]));  // no use of it may move above the wait
+        for (int t = 0; t < KC; t++) asm volatile("" : "+v"(landed[t]));  // no use of it may move above the wait
     };
 #define MV_PHASE(CUR, NXT, NX2)                                    \
     {                                                              \

@@ -724,6 +724,43 @@ def test_forced_kernel_paths_agree(cpa, hook, tuning):
         assert np.array_equal(_dev_matvec(cpa, f, A, m, k, x, True).reshape(wy.shape), wy), gname
 
 
+_MV_VALU_MODULI = _UNSAT_MODULI + [("goldilocks", 2**64 - 2**32 + 1, 1), ("p61 in one word", 2**61 - 1, 1), ("p128 h=1", 2**127 - 1, 2),
+                                    ("odd composite 384", 3 * (2**380 - 2**190 + 5) | 1, 6)]
+
+
+@pytest.mark.parametrize("kernel", [0, 1])
+@pytest.mark.parametrize("case", _MV_VALU_MODULI, ids=[c[0] for c in _MV_VALU_MODULI])
+def test_matvec_both_valu_kernels_every_width(cpa, tuning, case, kernel):
+    """The two VALU mat-vec kernels -- k_matvec (saturated words, a wide add per term) and k_matvec_cols (round 3:
+    unsaturated 29-bit limbs, carry-free column sums across the terms of a row, one row per wave, the exact integer
+    reduced once per row) -- forced with FPGPU_MATVEC_COLS at every compiled width, on tight, roomy and composite
+    moduli: rows of 1 ... 4099 columns (shorter than a wave, ragged against 64 lanes, long enough for several
+    normalisations of the columns: 63 / L terms each), all-extreme rows (every product (p - 1)^2: the largest column
+    sums), rows of zeros, more rows than one launch's waves take in one pass."""
+    from oracle.fp_oracle import Oracle
+    _, p, n64 = case
+    tuning("FPGPU_MATVEC_COLS", kernel)
+    f, o = cpa.MontyField(p, n64), Oracle(p, n64)
+    rnd = random.Random(p % 1000003 + kernel)
+    edge = [0, 1, 2, p - 1, p - 2, p >> 1, (p >> 1) + 1]
+    for rows, cols in ((1, 1), (3, 63), (5, 64), (7, 65), (2, 130), (9, 4099), (300, 17)):
+        A = [rnd.choice(edge) if rnd.random() < 0.2 else rnd.randrange(p) for _ in range(rows * cols)]
+        x = [rnd.choice(edge) if rnd.random() < 0.2 else rnd.randrange(p) for _ in range(cols)]
+        A[:cols] = [p - 1] * cols                    # row 0: the largest products throughout (when x is)
+        if rows > 1:
+            A[cols:2 * cols] = [0] * cols            # row 1: nothing
+        if rows == 9:
+            x = [p - 1] * cols
+        A, x = ints_to_array(A, n64), ints_to_array(x, n64)
+        want = o.matvec(A, rows, cols, x, threads=0)
+        assert np.array_equal(_dev_matvec(cpa, f, A, rows, cols, x, False).reshape(want.shape), want), (rows, cols)
+    rows, cols = 70003, 3                            # one row per wave: far more rows than waves in a pass of the grid cap
+    A = ints_to_array([rnd.randrange(p) for _ in range(rows * cols)], n64)
+    x = ints_to_array([rnd.randrange(p) for _ in range(cols)], n64)
+    want = o.matvec(A, rows, cols, x, threads=0)
+    assert np.array_equal(_dev_matvec(cpa, f, A, rows, cols, x, False).reshape(want.shape), want)
+
+
 @pytest.mark.parametrize("case", _UNSAT_MODULI, ids=[c[0] for c in _UNSAT_MODULI])
 def test_every_width_elementwise_fold_matvec_spmv(cpa, case):
     """Every compiled width (n64 = 3, 5, 7, 8 included, tight and roomy moduli) through the kernels the
