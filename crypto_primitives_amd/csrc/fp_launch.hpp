@@ -36,6 +36,8 @@ constexpr size_t kInvLanesWanted = 65536;   // one wave per SIMD
 constexpr size_t kInvTop = 65536; // stop recursing when this few totals remain: one exact inversion per lane is
                                   // pure latency up to one wave per SIMD (2^13 lanes 91 us, 2^16 lanes 103 us on
                                   // 2^24 BLS12-381 elements), a tree level costs 45 us
+constexpr size_t kInvOneLevelMax = 84 * kInvTop;   // 5.5 M elements: up to here one level with chains of n / 65536 wins (make_inv_plan)
+constexpr size_t kInvStretchMax = 48;              // longest level-0 chain chosen to spare a third level
 constexpr int kInvMaxLevels = 16;
 constexpr int kInvTopChainMaxC = 8;   // longest chain of the last stored level that rides in the top kernel (k_binv_top_chain's LDS is sized by it)
 struct InvPlan {

@@ -146,6 +146,18 @@ InvPlan make_inv_plan(uint32_t n64, size_t n) {
         size_t c = p.count[p.levels];
         int len = kInvCMin;
         while (len < kInvCMax && c / (2 * (size_t)len) >= kInvLanesWanted) len *= 2;
+        if (p.levels == 0) {
+            // A tree level costs 80-100 us beside sweeps of 100-300 us (tools/exp_binv_threshold.py, BLS12-381: 2^21 + 1
+            // elements 291 us with chains of 32 and a second level, 192 us with chains of 33 and none; 600 000: 145 -> 108;
+            // 70 000: 97 -> 79 with chains of 2).  Up to kInvOneLevelMax elements the level-0 chains are therefore just
+            // long enough for the totals to fit the top kernel (one level, the fewest multiplications that allows);
+            // beyond, where chains of 90 and more lose to two levels, they are stretched only as far as it takes for
+            // the level above to finish the tree (2^24 + 1 elements: 33 and 8, not 32, 8 and 8).
+            const size_t one = (c + kInvTop - 1) / kInvTop;
+            const size_t two = (c + (size_t)kInvCMin * kInvTop - 1) / ((size_t)kInvCMin * kInvTop);
+            if (c <= kInvOneLevelMax) len = (int)(one < 2 ? 2 : one);
+            else if (two > (size_t)len && two <= kInvStretchMax) len = (int)two;
+        }
         if (const long v = tuning().inv_c; v >= 2 && v <= 1024) len = (int)v;  // tuning / tests
         if (const long v = tuning().inv_c0; p.levels == 0 && v >= 2 && v <= 1024) len = (int)v;
         p.c[p.levels] = len;
@@ -158,6 +170,25 @@ InvPlan make_inv_plan(uint32_t n64, size_t n) {
     for (int l = 1; l < p.levels; l++) p.o_off[l] = take(p.count[l] * esz);
     p.poison_off = take(p.count[p.levels]);
     p.any_off = take(sizeof(uint32_t));
+    // The size REPORTED never shrinks as n grows: a caller sizes a workspace for its largest batch and then inverts
+    // shorter ones in it (the chunk pipeline's last chunk, the static scratch, a serving loop) -- while the layout
+    // above does shrink where a longer chain takes over (65 537 totals at 131 073 elements in chains of 2, 43 691 at
+    // 131 074 in chains of 3).  The bound: the most totals any shorter batch can have at each level under the rules
+    // above (hooks aside), laid out the same way.
+    {
+        size_t bound = 0;
+        auto put = [&](size_t bytes) { bound += (bytes + 255) & ~(size_t)255; };
+        size_t cl = n <= kInvOneLevelMax ? ((n + 1) / 2 < kInvTop ? (n + 1) / 2 : kInvTop) : (n + kInvCMax - 1) / kInvCMax;
+        for (int l = 1; l <= kInvMaxLevels; l++) {
+            put(cl * esz);                       // X_l
+            if (cl <= kInvTop) break;
+            put(cl * esz);                       // O_l (every level but the last)
+            cl = (cl + kInvCMin - 1) / kInvCMin;
+        }
+        put(kInvTop);                            // poison flags of the top
+        put(sizeof(uint32_t));
+        if (bound > off) off = bound;
+    }
     p.bytes = off;
     // the last stored level rides in the top kernel when its chains are short (then that level's own prefix
     // array O_l is still what the level below reads its inverted totals from; X_(l+1) goes unused)

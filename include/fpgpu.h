@@ -157,12 +157,13 @@ int fpgpu_product_dev(const fpgpu_ctx *ctx, const void *v, size_t n, void *out, 
  * Montgomery's trick.  Where the reference returns None (x[i] == 0, or not
  * invertible for a composite modulus) out[i] = 0 and zero_flags[i] = 1;
  * elsewhere zero_flags[i] = 0.  zero_flags (n bytes, device) may be NULL.
- * `workspace` is device scratch of fpgpu_batch_inv_workspace_bytes(ctx, n) bytes. */
+ * `workspace` is device scratch of fpgpu_batch_inv_workspace_bytes(ctx, n) bytes.  Both sizes below never shrink
+ * as n grows: a workspace sized for the largest batch serves every shorter one. */
 size_t fpgpu_batch_inv_workspace_bytes(const fpgpu_ctx *ctx, size_t n);
 /* A workspace of at least this size (instead of the minimum above; about 4 * (n64 * 2 + 2 .. 3) more bytes
  * per element) lets the level-0 prefix products stay in the multiplier's own 29-bit-limb form in the
  * workspace instead of going through the output array as words: same results, a few per cent faster
- * (2^24 BLS12-381 elements: 1.07 -> 1.04 ms).  Equal to the minimum for n64 <= 2.  fpgpu_batch_inv_dev and
+ * (2^24 BLS12-381 elements: 1.07 -> 1.04 ms).  Equal to the minimum below 384 bits (n64 <= 5), where the limb form does not pay.  fpgpu_batch_inv_dev and
  * fpgpu_div_dev pick the path by the `workspace_bytes` they are given. */
 size_t fpgpu_batch_inv_fast_workspace_bytes(const fpgpu_ctx *ctx, size_t n);
 int fpgpu_batch_inv_dev(const fpgpu_ctx *ctx, const void *x, void *out, uint8_t *zero_flags, size_t n,
