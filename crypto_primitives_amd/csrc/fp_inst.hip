@@ -143,7 +143,19 @@ hipError_t Launch<N>::matvec(const fpgpu_ctx* ctx, const void* A, size_t rows, s
         MvPlan pl = make_mv_plan(ctx->n64, rows, cols);
         const long ksp = tune.matvec_ksplit;  // tuning / test hook: column parts per row block
         if (ksp > 0 && pl.usable) pl.ksplit = (uint32_t)ksp < pl.chunks_total ? (uint32_t)ksp : pl.chunks_total;
-        if (pl.usable && workspace && workspace_bytes >= pl.bytes && tune.matvec_mfma != 0 && (uintptr_t)A % 16 == 0) {
+        const bool cores = pl.usable && workspace && workspace_bytes >= pl.bytes && tune.matvec_mfma != 0 && (uintptr_t)A % 16 == 0;
+        // Many short rows: one row per lane (k_matvec_rows: no cross-lane sum, the per-row reduction once per lane).
+        // Measured on 4 GiB matrices (tools/time_matvec_tall.py, TB/s, row per lane / matrix cores / row per wave):
+        // BN254 16 columns 3.59 / 0.81 / 0.19, 64: 3.93 / 2.53 / 0.73, 128: 3.87 / 3.33 / 1.32, 256: 4.06 / 4.02 / 2.11,
+        // 512: 4.25 / 4.27 / 2.98; BLS12-381 64: 2.92 / 2.46 / 0.46, 128: 2.92 / 3.12 / 0.80, 512: 3.02 / 3.91 / 2.24;
+        // Goldilocks 64: 2.77 / 2.30 / 0.72, 128: 2.42 / 3.24 / 1.35, 256: 2.30 / 4.01 / 2.31.
+        const size_t widest = cores ? (N == 8 ? 128 : 64) : (N >= 8 ? 512 : 256);
+        if (tune.matvec_rows >= 0 ? tune.matvec_rows == 1 : (cols <= widest && rows >= kMvRowsMinRows)) {
+            hipLaunchKernelGGL((k_matvec_rows<N>), dim3(grid_for(rows)), dim3(kBlock), 0, s, (const uint32_t*)A, (const uint32_t*)x,
+                               (uint32_t*)y, rows, cols, make_params<N>(ctx));
+            return hipSuccess;
+        }
+        if (cores) {
             constexpr int NT = N / 2;
             uint8_t* ws = (uint8_t*)workspace;
             uint32_t* flag = (uint32_t*)ws;
@@ -188,10 +200,23 @@ hipError_t Launch<N>::matvec(const fpgpu_ctx* ctx, const void* A, size_t rows, s
     // 320 bits 4.20 / 4.14, BLS12-381 3.78 / 4.09; 448 bits 3.44 / 3.19 and 512 bits 3.16 / 3.12 with 256 registers
     // and one wave per SIMD; one and two words 4.69 / 4.66 and 5.37 / 5.39).  FPGPU_MATVEC_COLS forces either.
     const bool cols_kernel = tune.matvec_cols >= 0 ? tune.matvec_cols == 1 : (N >= 6 && N <= 12);
-    if (cols_kernel && t_env <= 1) {
-        const size_t wgs = (rows + kBlock / 64 - 1) / (kBlock / 64);
+    // few long rows (not the matrix cores' shapes) with a workspace: column parts, then a sum per row -- at every width
+    uint32_t parts = 1;
+    if (!gate && workspace && tune.matvec_cols != 0) {
+        parts = mv_split_parts(rows, cols);
+        if (parts > 1 && workspace_bytes < mv_split_bytes(ctx->n64, rows, cols)) parts = 1;
+    }
+    if ((cols_kernel || parts > 1) && t_env <= 1) {
+        const size_t per_part = parts > 1 ? ((cols + parts - 1) / parts + 63) / 64 * 64 : cols;
+        const size_t items = rows * parts, wgs = (items + kBlock / 64 - 1) / (kBlock / 64);
         const int g2 = (int)(wgs < grid_cap ? (wgs ? wgs : 1) : grid_cap);
-        hipLaunchKernelGGL((k_matvec_cols<N>), dim3(g2), dim3(kBlock), 0, s, Ap, xp, yp, rows, cols, gate, make_params<N>(ctx));
+        hipLaunchKernelGGL((k_matvec_cols<N>), dim3(g2), dim3(kBlock), 0, s, Ap, xp, parts > 1 ? (uint32_t*)workspace : yp, rows, cols,
+                           gate, make_params<N>(ctx), parts, per_part);
+        if (parts > 1) {
+            const size_t cw = (rows + kBlock / 64 - 1) / (kBlock / 64);
+            hipLaunchKernelGGL((k_matvec_combine<N>), dim3((unsigned)(cw ? cw : 1)), dim3(kBlock), 0, s, (const uint32_t*)workspace, yp,
+                               rows, parts, make_params<N>(ctx));
+        }
         return hipSuccess;
     }
     if (T >= 4)

@@ -693,13 +693,21 @@ __global__ __launch_bounds__(kBlock) void k_matvec(const uint32_t* __restrict__ 
 template <int N>
 __global__ __launch_bounds__(kBlock) void k_matvec_cols(const uint32_t* __restrict__ A, const uint32_t* __restrict__ x,
                                                         uint32_t* __restrict__ y, size_t rows, size_t cols,
-                                                        const uint32_t* __restrict__ run_if_set, const FpParams<N> P) {
+                                                        const uint32_t* __restrict__ run_if_set, const FpParams<N> P,
+                                                        uint32_t parts, size_t per_part) {
     constexpr int L = UF<N>::L, NC = 2 * L + 2, TT = 63 / L;   // TT * L products of < 2^58 and a carry fit 64 bits
     constexpr uint32_t M = UF<N>::C::MASK;
     if (run_if_set && *run_if_set == 0) return;
     const int lane = threadIdx.x & 63;
     const size_t waves = (size_t)gridDim.x * (kBlock / 64);
-    for (size_t row = (size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); row < rows; row += waves) {
+    // parts > 1 (few rows, long ones): a wave takes columns [part * per_part, (part + 1) * per_part) of its row and
+    // writes the canonical residue of that partial sum to y[row * parts + part] -- y is then the launcher's scratch,
+    // and k_matvec_combine adds a row's partials (the sum is the same canonical residue however it is split)
+    const size_t items = rows * parts;
+    for (size_t item = (size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); item < items; item += waves) {
+        const size_t row = parts > 1 ? item / parts : item;
+        const size_t cbeg = parts > 1 ? (item % parts) * per_part : 0;
+        const size_t cend = parts > 1 && cbeg + per_part < cols ? cbeg + per_part : cols;
         const uint32_t* __restrict__ Arow = A + row * cols * N;
         uint64_t c[NC];
 #pragma unroll
@@ -712,8 +720,8 @@ __global__ __launch_bounds__(kBlock) void k_matvec_cols(const uint32_t* __restri
             }
         };
         uint32_t va[N], vx[N];
-        size_t j = lane;
-        bool have = j < cols;
+        size_t j = cbeg + lane;
+        bool have = j < cend;
         if (have) {
             load_elem<N>(va, Arow, j);
             load_elem<N>(vx, x, j);
@@ -724,7 +732,7 @@ __global__ __launch_bounds__(kBlock) void k_matvec_cols(const uint32_t* __restri
             uload<N>(a, va);
             uload<N>(b, vx);
             const size_t jn = j + 64;
-            const bool hn = jn < cols;
+            const bool hn = jn < cend;
             if (hn) {   // in flight over this element's multiplies
                 load_elem<N>(va, Arow, jn);
                 load_elem<N>(vx, x, jn);
@@ -762,6 +770,98 @@ __global__ __launch_bounds__(kBlock) void k_matvec_cols(const uint32_t* __restri
         mont_mul<N>(t2, w2, r2, P);
         mod_add<N>(s, t0, t1, P);
         mod_add<N>(acc, s, t2, P);
+        if (lane == 0) store_elem<N>(y, item, acc);
+    }
+}
+// ---- dense mat-vec, one row per LANE: many short rows (tall, narrow matrices) -------------------------------
+// k_matvec_cols pays a wave-wide sum and one reduction per ROW of 64 lanes; with 16 or 64 columns that is most of its
+// instructions (2^21 rows x 64 columns: 0.73 TB/s).  Here a lane owns a row: the same carry-free column sums, no
+// cross-lane step at all, and the per-row reduction runs once per lane.  x[j] is the same address in every lane (a
+// scalar load; its limbs are wave-uniform); a lane walks its own row U elements at a time, i.e. whole 128-byte lines,
+// and the 64 rows of a wave are one contiguous piece of the matrix.
+template <int N>
+__global__ __launch_bounds__(kBlock) void k_matvec_rows(const uint32_t* __restrict__ A, const uint32_t* __restrict__ x,
+                                                        uint32_t* __restrict__ y, size_t rows, size_t cols, const FpParams<N> P) {
+    constexpr int L = UF<N>::L, NC = 2 * L + 2, TT = 63 / L, U = N <= 8 ? 4 : 2;
+    constexpr uint32_t M = UF<N>::C::MASK;
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t row = (size_t)blockIdx.x * kBlock + threadIdx.x; row < rows; row += stride) {
+        const uint32_t* __restrict__ Arow = A + row * cols * N;
+        uint64_t c[NC];
+#pragma unroll
+        for (int i = 0; i < NC; i++) c[i] = 0;
+        auto normalise = [&]() {
+#pragma unroll
+            for (int i = 0; i + 1 < NC; i++) {
+                c[i + 1] += c[i] >> kUB;
+                c[i] &= M;
+            }
+        };
+        int pending = 0;
+        auto term = [&](const uint32_t (&va)[N], size_t j) {
+            uint32_t vx[N], a[L], b[L];
+            load_elem<N>(vx, x, j);
+            uload<N>(a, va);
+            uload<N>(b, vx);
+#pragma unroll
+            for (int i = 0; i < L; i++)
+#pragma unroll
+                for (int k = 0; k < L; k++) c[i + k] += (uint64_t)a[i] * b[k];
+            if (++pending == TT) {
+                normalise();
+                pending = 0;
+            }
+        };
+        size_t j = 0;
+        for (; j + U <= cols; j += U) {
+            uint32_t va[U][N];
+#pragma unroll
+            for (int u = 0; u < U; u++) load_elem<N>(va[u], Arow, j + u);
+#pragma unroll
+            for (int u = 0; u < U; u++) term(va[u], j + u);
+        }
+        for (; j < cols; j++) {
+            uint32_t va[N];
+            load_elem<N>(va, Arow, j);
+            term(va, j);
+        }
+        normalise();
+        normalise();
+        uint32_t limbs[NC], w[3 * N];
+#pragma unroll
+        for (int i = 0; i < NC; i++) limbs[i] = (uint32_t)c[i];
+        from_limbs<3 * N, kUB, NC>(w, limbs);
+        uint32_t w0[N], w1[N], w2[N], one[N], r1[N], r2[N], t0[N], t1[N], t2[N], s[N], acc[N];
+#pragma unroll
+        for (int l = 0; l < N; l++) { w0[l] = w[l]; w1[l] = w[N + l]; w2[l] = w[2 * N + l]; one[l] = l == 0 ? 1u : 0u; }
+        set_limbs<N>(r1, P.one);
+        set_limbs<N>(r2, P.r2);
+        mont_mul<N>(t0, w0, one, P);
+        mont_mul<N>(t1, w1, r1, P);
+        mont_mul<N>(t2, w2, r2, P);
+        mod_add<N>(s, t0, t1, P);
+        mod_add<N>(acc, s, t2, P);
+        store_elem<N>(y, row, acc);
+    }
+}
+
+// y[row] = sum of the row's `parts` partial residues (one wave per row)
+template <int N>
+__global__ __launch_bounds__(kBlock) void k_matvec_combine(const uint32_t* __restrict__ partial, uint32_t* __restrict__ y,
+                                                           size_t rows, uint32_t parts, const FpParams<N> P) {
+    const int lane = threadIdx.x & 63;
+    const size_t waves = (size_t)gridDim.x * (kBlock / 64);
+    for (size_t row = (size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); row < rows; row += waves) {
+        uint32_t acc[N], v[N], t[N];
+#pragma unroll
+        for (int l = 0; l < N; l++) acc[l] = 0;
+        for (uint32_t i = lane; i < parts; i += 64) {
+            load_elem<N>(v, partial, row * parts + i);
+            mod_add<N>(t, acc, v, P);
+#pragma unroll
+            for (int l = 0; l < N; l++) acc[l] = t[l];
+        }
+        wave_reduce_add<N>(acc, P);
         if (lane == 0) store_elem<N>(y, row, acc);
     }
 }

@@ -104,6 +104,22 @@ inline MvPlan make_mv_plan(uint32_t n64, size_t rows, size_t cols) {
     pl.bytes = pl.b_off + (size_t)pl.chunks_total * kc * pl.nt * 1024;
     return pl;
 }
+// VALU mat-vec with few, long rows (shapes the matrix-core plan does not take: more than 2^23 bytes per row): one row per
+// wave would leave the chip empty (128 rows x 2^20 BN254 columns: 0.5 TB/s; one row: one wave), so the columns are split
+// over `parts` waves per row and the canonical partial residues go through the workspace (k_matvec_cols, k_matvec_combine).
+constexpr size_t kMvRowsMinRows = 65536;   // k_matvec_rows (one row per lane) takes matrices at least this tall: a wave per SIMD
+inline uint32_t mv_split_parts(size_t rows, size_t cols) {
+    constexpr size_t kWavesWanted = 8192;   // two per SIMD
+    if (rows == 0 || rows >= kWavesWanted / 2 || cols < 1024) return 1;
+    size_t parts = (kWavesWanted + rows - 1) / rows;
+    const size_t most = cols / 512;         // a part is at least 8 elements per lane
+    if (parts > most) parts = most;
+    return parts < 2 ? 1 : (uint32_t)parts;
+}
+inline size_t mv_split_bytes(uint32_t n64, size_t rows, size_t cols) {
+    const uint32_t parts = mv_split_parts(rows, cols);
+    return parts < 2 ? 0 : ((rows * parts * 8 * (size_t)n64 + 255) / 256) * 256;
+}
 // Workspace of the matrix-core mat-mul (fp_matmul_mfma.cuh): a flag word, then the int8 digit
 // planes of A and of B^T in 64-row blocks x 64-deep k-steps x 32 KiB.
 struct MfmaPlan {
@@ -139,6 +155,7 @@ struct Tuning {
     long matvec_mfma = -1;    // FPGPU_MATVEC_MFMA: 0 forces the VALU mat-vec
     long matvec_ksplit = 0;   // FPGPU_MATVEC_KSPLIT: column parts per row block (matrix-core mat-vec)
     long matvec_t = 0;        // FPGPU_MATVEC_T: products per pass of the VALU mat-vec
+    long matvec_rows = -1;    // FPGPU_MATVEC_ROWS: 1 = one row per lane (k_matvec_rows) whatever the shape, 0 = never; -1 = tall narrow matrices
     long matvec_cols = -1;    // FPGPU_MATVEC_COLS: 1 = VALU mat-vec on unsaturated column sums (k_matvec_cols), 0 = k_matvec; -1 = the launcher's choice
     long matmul_mfma = -1;    // FPGPU_MATMUL_MFMA: 0 forces the VALU single-limb mat-mul
     long matmul_generic = 0;  // FPGPU_MATMUL_GENERIC: 1 forces the multi-limb mat-mul kernel

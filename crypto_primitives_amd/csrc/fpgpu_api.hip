@@ -112,6 +112,7 @@ static const TuningEntry kTuningEntries[] = {
     {"FPGPU_POW_WINDOW", &Tuning::pow_window},         {"FPGPU_SPMV_UNROLL", &Tuning::spmv_unroll},
     {"FPGPU_INV_C0", &Tuning::inv_c0},                 {"FPGPU_INV_FUSE_TOP", &Tuning::inv_fuse_top},
     {"FPGPU_INV_LP", &Tuning::inv_lp},                 {"FPGPU_MATVEC_COLS", &Tuning::matvec_cols},
+    {"FPGPU_MATVEC_ROWS", &Tuning::matvec_rows},
 };
 static Tuning g_tuning_defaults;
 static Tuning g_tuning;
@@ -414,7 +415,7 @@ int fpgpu_batch_inv_static_dev(const fpgpu_ctx* ctx, const void* x, void* out, u
 size_t fpgpu_matvec_workspace_bytes(const fpgpu_ctx* ctx, size_t rows, size_t cols) {
     if (!ctx) return 0;
     const MvPlan pl = make_mv_plan(ctx->n64, rows, cols);
-    return pl.usable ? pl.bytes : 0;
+    return pl.usable ? pl.bytes : mv_split_bytes(ctx->n64, rows, cols);   // few long rows outside the plan: scratch for column parts
 }
 
 int fpgpu_matvec_dev(const fpgpu_ctx* ctx, const void* A, size_t rows, size_t cols, const void* x, void* y,

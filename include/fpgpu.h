@@ -197,7 +197,11 @@ int fpgpu_batch_inv_static_dev(const fpgpu_ctx *ctx, const void *x, void *out, u
  * `workspace` is optional device scratch (256-byte aligned) of at least
  * fpgpu_matvec_workspace_bytes(ctx, rows, cols) bytes; with it the products run on the matrix
  * cores (A streamed once, as it lies) and the call is HBM-bound; without it (NULL), or where
- * that size is 0, the VALU kernel runs.  Results are identical. */
+ * that size is 0, a VALU kernel runs.  Results are identical.  The launcher picks the kernel by
+ * shape: tall, narrow matrices go one row per lane (no workspace needed); a few very long rows
+ * (more than 2^23 bytes each: outside the matrix-core plan) are split over columns through the
+ * workspace -- such shapes NEED it to fill the GPU (one row of 2^27 elements: 2.8 TB/s with it,
+ * one wave without). */
 size_t fpgpu_matvec_workspace_bytes(const fpgpu_ctx *ctx, size_t rows, size_t cols);
 int fpgpu_matvec_dev(const fpgpu_ctx *ctx, const void *A, size_t rows, size_t cols, const void *x,
                      void *y, void *workspace, size_t workspace_bytes, void *stream);
@@ -382,7 +386,7 @@ int fpgpu_vec_spmv(const fpgpu_ctx *ctx, const fpgpu_vec *vals, const fpgpu_idx 
 
 /* ---- tuning / test hooks -----------------------------------------------------
  * No counterpart in the reference.  The hooks of INTEGRATION.md section 4 (FPGPU_GRID_CAP,
- * FPGPU_INV_C, FPGPU_INV_C0, FPGPU_INV_FUSE_TOP, FPGPU_INV_LP, FPGPU_MATVEC_MFMA, FPGPU_MATVEC_KSPLIT, FPGPU_MATVEC_T, FPGPU_MATVEC_COLS, FPGPU_MATMUL_MFMA,
+ * FPGPU_INV_C, FPGPU_INV_C0, FPGPU_INV_FUSE_TOP, FPGPU_INV_LP, FPGPU_MATVEC_MFMA, FPGPU_MATVEC_KSPLIT, FPGPU_MATVEC_T, FPGPU_MATVEC_COLS, FPGPU_MATVEC_ROWS, FPGPU_MATMUL_MFMA,
  * FPGPU_MATMUL_GENERIC, FPGPU_SPMV_LOG2G, FPGPU_SPMV_UNROLL, FPGPU_ALLGATHER_COPY, FPGPU_COPY_THREADS, FPGPU_POW_WINDOW) are read from the environment once, when the library
  * is first used; this call sets one afterwards (process-wide; FPGPU_TUNING_DEFAULT restores the
  * library's choice).  No hook changes a result -- they pick between bit-identical paths.  Not

@@ -23,20 +23,22 @@ from oracle.fp_oracle import Oracle  # noqa: E402
 
 
 def rand_elems(rng, n, n64, p):
-    """n uniform residues below p as an (n, n64) uint64 array (rejection on the top word only: cheap)."""
+    """n residues below p as an (n, n64) uint64 array: uniform words masked to p's bit length, the (fewer than half)
+    rows that come out >= p get their top bit cleared (p has that bit set, so they end up below it)."""
     w = rng.integers(0, 1 << 64, size=(n, n64), dtype=np.uint64)
-    top_bits = p.bit_length() - 64 * (n64 - 1)
-    w[:, n64 - 1] &= np.uint64((1 << top_bits) - 1)
-    # fix the rows that are >= p by clearing their top bit (keeps them below p since p has that bit set)
+    top = (p.bit_length() - 1) // 64                    # the word that holds p's top bit (the container may be wider)
+    top_bits = p.bit_length() - 64 * top
+    w[:, top + 1:] = 0
+    w[:, top] &= np.uint64((1 << top_bits) - 1)
     pw = [(p >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(n64)]
     ge = np.ones(n, dtype=bool)      # lexicographic compare from the top word
     decided = np.zeros(n, dtype=bool)
-    for i in reversed(range(n64)):
+    for i in reversed(range(top + 1)):
         gt = (w[:, i] > np.uint64(pw[i])) & ~decided
         lt = (w[:, i] < np.uint64(pw[i])) & ~decided
         ge[lt] = False
         decided |= gt | lt
-    w[ge, n64 - 1] &= np.uint64((1 << (top_bits - 1)) - 1)
+    w[ge, top] &= np.uint64((1 << (top_bits - 1)) - 1)
     return w
 
 

@@ -724,6 +724,29 @@ def test_forced_kernel_paths_agree(cpa, hook, tuning):
         assert np.array_equal(_dev_matvec(cpa, f, A, m, k, x, True).reshape(wy.shape), wy), gname
 
 
+@pytest.mark.parametrize("name,p,n64,rows,cols", [
+    ("bn254", 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001, 4, 1, 300001),
+    ("bn254", 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001, 4, 37, 262145),
+    ("bls12_381", 0x1A0111EA397FE69A4B1BA7B6434BACD764774B84F38512BF6730D2A0F6B0F6241EABFFFEB153FFFFB9FEFFFFFFFFAAAB, 6, 3, 200000),
+    ("goldilocks", 2**64 - 2**32 + 1, 1, 2, 1500007), ("p512", 2**512 - 569, 8, 5, 140000), ("p448", 2**448 - 2**224 - 1, 7, 1, 160003)])
+def test_matvec_few_long_rows_split_over_columns(cpa, name, p, n64, rows, cols):
+    """Rows longer than the matrix-core plan takes (more than 2^23 bytes) and too few to give every SIMD a wave: with
+    the workspace fpgpu_matvec_workspace_bytes reports for such shapes the VALU kernel splits the columns over many
+    waves per row (ragged last part, parts that start past the row's end) and k_matvec_combine adds the partial
+    residues; without it the same kernel takes whole rows.  Both against the oracle, bit for bit."""
+    from oracle.fp_oracle import Oracle
+    f, o = cpa.MontyField(p, n64), Oracle(p, n64)
+    rng = np.random.default_rng(rows * 1000 + n64)
+    from soak_inversion_plans import rand_elems
+    A, x = rand_elems(rng, rows * cols, n64, p), rand_elems(rng, cols, n64, p)
+    A[:3], x[:2] = ints_to_array([p - 1, 0, 1], n64), ints_to_array([p - 1, p - 2], n64)
+    want = o.matvec(A, rows, cols, x, threads=0)
+    assert f.matvec_workspace_bytes(rows, cols) >= rows * 2 * 8 * n64, "no split workspace reported for this shape"
+    assert np.array_equal(_dev_matvec(cpa, f, A, rows, cols, x, True).reshape(want.shape), want), "column parts"
+    assert np.array_equal(_dev_matvec(cpa, f, A, rows, cols, x, False).reshape(want.shape), want), "whole rows"
+    assert np.array_equal(f.matvec(A, rows, cols, x), want), "host call"
+
+
 _MV_VALU_MODULI = _UNSAT_MODULI + [("goldilocks", 2**64 - 2**32 + 1, 1), ("p61 in one word", 2**61 - 1, 1), ("p128 h=1", 2**127 - 1, 2),
                                     ("odd composite 384", 3 * (2**380 - 2**190 + 5) | 1, 6)]
 
@@ -759,6 +782,37 @@ def test_matvec_both_valu_kernels_every_width(cpa, tuning, case, kernel):
     x = ints_to_array([rnd.randrange(p) for _ in range(cols)], n64)
     want = o.matvec(A, rows, cols, x, threads=0)
     assert np.array_equal(_dev_matvec(cpa, f, A, rows, cols, x, False).reshape(want.shape), want)
+
+
+@pytest.mark.parametrize("case", _MV_VALU_MODULI, ids=[c[0] for c in _MV_VALU_MODULI])
+def test_matvec_one_row_per_lane_every_width(cpa, tuning, case):
+    """k_matvec_rows (round 3: tall, narrow matrices -- a lane owns a row, x[j] is a scalar load, no cross-lane step):
+    forced with FPGPU_MATVEC_ROWS = 1 on shapes of every kind (one column, column counts around its unroll of 4 / 2,
+    more columns than one normalisation interval, fewer rows than a wave, all-extreme rows), then chosen by the
+    launcher itself on a 70 003 x 5 matrix with and without a workspace; against the oracle bit for bit."""
+    from oracle.fp_oracle import Oracle
+    _, p, n64 = case
+    f, o = cpa.MontyField(p, n64), Oracle(p, n64)
+    rnd = random.Random(p % 1000003)
+    edge = [0, 1, 2, p - 1, p - 2, p >> 1]
+    tuning("FPGPU_MATVEC_ROWS", 1)
+    for rows, cols in ((1, 1), (3, 2), (65, 3), (7, 4), (130, 5), (9, 33), (300, 70), (2, 1000)):
+        A = [rnd.choice(edge) if rnd.random() < 0.2 else rnd.randrange(p) for _ in range(rows * cols)]
+        x = [rnd.choice(edge) if rnd.random() < 0.2 else rnd.randrange(p) for _ in range(cols)]
+        A[:cols] = [p - 1] * cols
+        if rows == 9:
+            x = [p - 1] * cols
+        A, x = ints_to_array(A, n64), ints_to_array(x, n64)
+        want = o.matvec(A, rows, cols, x, threads=0)
+        assert np.array_equal(_dev_matvec(cpa, f, A, rows, cols, x, False).reshape(want.shape), want), (rows, cols)
+    tuning("FPGPU_MATVEC_ROWS", -1)                    # the launcher's own choice
+    rows, cols = 70003, 5
+    rng = np.random.default_rng(n64)
+    from soak_inversion_plans import rand_elems
+    A, x = rand_elems(rng, rows * cols, n64, p), rand_elems(rng, cols, n64, p)
+    want = o.matvec(A, rows, cols, x, threads=0)
+    for use_ws in (False, True):
+        assert np.array_equal(_dev_matvec(cpa, f, A, rows, cols, x, use_ws).reshape(want.shape), want), use_ws
 
 
 @pytest.mark.parametrize("case", _UNSAT_MODULI, ids=[c[0] for c in _UNSAT_MODULI])
