@@ -231,6 +231,18 @@ hipError_t Launch<N>::matvec(const fpgpu_ctx* ctx, const void* A, size_t rows, s
 template <int N>
 hipError_t Launch<N>::matmul(const fpgpu_ctx* ctx, const void* A, const void* B, void* C, size_t m, size_t k, size_t n,
                        void* workspace, size_t workspace_bytes, hipStream_t s) {
+    // a small output over a long k, with the scratch for it: k split over workgroups (every width, the multi-limb kernel)
+    if (const uint32_t parts = mm_split_parts(m, k, n);
+        parts > 1 && workspace && workspace_bytes >= mm_split_bytes(ctx->n64, m, k, n) ) {
+        const size_t kper = ((k + parts - 1) / parts + kMMTile - 1) / kMMTile * kMMTile;
+        const size_t gx = (n + kMMTile - 1) / kMMTile, gy = (m + kMMTile - 1) / kMMTile;
+        hipLaunchKernelGGL((k_matmul<N>), dim3((unsigned)gx, (unsigned)gy, parts), dim3(kMMTile * kMMTile), 0, s,
+                           (const uint32_t*)A, (const uint32_t*)B, (uint32_t*)workspace, m, k, n, make_params<N>(ctx), parts, kper);
+        const size_t outs = m * n, cw = (outs + kBlock / 64 - 1) / (kBlock / 64);
+        hipLaunchKernelGGL((k_matvec_combine<N>), dim3((unsigned)cw), dim3(kBlock), 0, s, (const uint32_t*)workspace, (uint32_t*)C,
+                           outs, parts, make_params<N>(ctx));
+        return hipSuccess;
+    }
 #if FPGPU_N == 2
     {
         // single-limb paths; the tuning hooks matmul_generic = 1 force the generic kernel,
@@ -268,7 +280,7 @@ hipError_t Launch<N>::matmul(const fpgpu_ctx* ctx, const void* A, const void* B,
     (void)workspace_bytes;
     size_t gx = (n + kMMTile - 1) / kMMTile, gy = (m + kMMTile - 1) / kMMTile;
     hipLaunchKernelGGL((k_matmul<N>), dim3((unsigned)gx, (unsigned)gy), dim3(kMMTile * kMMTile), 0, s,
-                       (const uint32_t*)A, (const uint32_t*)B, (uint32_t*)C, m, k, n, make_params<N>(ctx));
+                       (const uint32_t*)A, (const uint32_t*)B, (uint32_t*)C, m, k, n, make_params<N>(ctx), 1u, k);
     return hipSuccess;
 }
 

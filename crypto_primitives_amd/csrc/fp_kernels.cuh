@@ -951,7 +951,10 @@ template <int N>
 __global__ __launch_bounds__(kMMTile* kMMTile) void k_matmul(const uint32_t* __restrict__ A,
                                                              const uint32_t* __restrict__ B,
                                                              uint32_t* __restrict__ Cm, size_t m, size_t k, size_t n,
-                                                             const FpParams<N> P) {
+                                                             const FpParams<N> P, uint32_t kparts, size_t kper) {
+    // kparts > 1 (a small output over a long k: too few tiles to fill the chip): blockIdx.z takes the terms
+    // [z * kper, (z + 1) * kper) and writes the canonical residue of its partial sum to Cm[(row * n + col) * kparts + z]
+    // -- Cm is then the launcher's scratch, and k_matvec_combine adds the parts of every output
     constexpr int L = UF<N>::L, NC = 2 * L + 2, T = MMTerms<L>::T;
     constexpr uint32_t M = UF<N>::C::MASK;
     __shared__ uint32_t sA[kMMTile][kMMTile][L];
@@ -969,9 +972,11 @@ __global__ __launch_bounds__(kMMTile* kMMTile) void k_matmul(const uint32_t* __r
             c[i] &= M;
         }
     };
-    for (size_t k0 = 0; k0 < k; k0 += kMMTile) {
+    const size_t kb = kparts > 1 ? (size_t)blockIdx.z * kper : 0;
+    const size_t ke = kparts > 1 && kb + kper < k ? kb + kper : k;
+    for (size_t k0 = kb; k0 < ke; k0 += kMMTile) {
         uint32_t v[N], lv[L];
-        if (row < m && k0 + tx < k) load_elem<N>(v, A, row * k + k0 + tx);
+        if (row < m && k0 + tx < ke) load_elem<N>(v, A, row * k + k0 + tx);
         else {
 #pragma unroll
             for (int l = 0; l < N; l++) v[l] = 0;
@@ -979,7 +984,7 @@ __global__ __launch_bounds__(kMMTile* kMMTile) void k_matmul(const uint32_t* __r
         uload<N>(lv, v);
 #pragma unroll
         for (int l = 0; l < L; l++) sA[ty][tx][l] = lv[l];
-        if (k0 + ty < k && col < n) load_elem<N>(v, B, (k0 + ty) * n + col);
+        if (k0 + ty < ke && col < n) load_elem<N>(v, B, (k0 + ty) * n + col);
         else {
 #pragma unroll
             for (int l = 0; l < N; l++) v[l] = 0;
@@ -1021,7 +1026,7 @@ __global__ __launch_bounds__(kMMTile* kMMTile) void k_matmul(const uint32_t* __r
     mont_mul<N>(t2, w2, r2, P);
     mod_add<N>(s, t0, t1, P);
     mod_add<N>(acc, s, t2, P);
-    if (row < m && col < n) store_elem<N>(Cm, row * n + col, acc);
+    if (row < m && col < n) store_elem<N>(Cm, kparts > 1 ? (row * n + col) * kparts + blockIdx.z : row * n + col, acc);
 }
 
 

@@ -120,6 +120,22 @@ inline size_t mv_split_bytes(uint32_t n64, size_t rows, size_t cols) {
     const uint32_t parts = mv_split_parts(rows, cols);
     return parts < 2 ? 0 : ((rows * parts * 8 * (size_t)n64 + 255) / 256) * 256;
 }
+// Mat-mul with a small output over a long k: the 16 x 16 output tiles are too few to fill the chip (16 x 2^20 x 16: ONE
+// workgroup), so k is split over `parts` workgroups per tile and the canonical partial residues go through the workspace
+// (k_matmul with blockIdx.z, k_matvec_combine).  Every field width takes this path for such shapes.
+inline uint32_t mm_split_parts(size_t m, size_t k, size_t n) {
+    const size_t tiles = ((m + 15) / 16) * ((n + 15) / 16);
+    if (tiles == 0 || tiles > 128 || k < 4096) return 1;
+    size_t parts = (1024 + tiles - 1) / tiles;   // ~four workgroups per CU
+    const size_t most = k / 512;
+    if (parts > most) parts = most;
+    if (parts > 65535) parts = 65535;
+    return parts < 2 ? 1 : (uint32_t)parts;
+}
+inline size_t mm_split_bytes(uint32_t n64, size_t m, size_t k, size_t n) {
+    const uint32_t parts = mm_split_parts(m, k, n);
+    return parts < 2 ? 0 : ((m * n * parts * 8 * (size_t)n64 + 255) / 256) * 256;
+}
 // Workspace of the matrix-core mat-mul (fp_matmul_mfma.cuh): a flag word, then the int8 digit
 // planes of A and of B^T in 64-row blocks x 64-deep k-steps x 32 KiB.
 struct MfmaPlan {

@@ -455,6 +455,8 @@ int fpgpu_spmv_dev(const fpgpu_ctx* ctx, const void* vals, const uint32_t* col_i
 
 size_t fpgpu_matmul_workspace_bytes(const fpgpu_ctx* ctx, size_t m, size_t k, size_t n) {
     if (!ctx) return 0;
+    if (n == 1) return fpgpu_matvec_workspace_bytes(ctx, m, k);   // a mat-vec: served by its kernels
+    if (const size_t split = mm_split_bytes(ctx->n64, m, k, n)) return split;   // a small output over a long k: scratch for the k parts
     const MfmaPlan pl = make_mfma_plan(ctx->n64, m, k, n);
     return pl.usable ? pl.bytes : 0;
 }
@@ -464,6 +466,9 @@ int fpgpu_matmul_dev(const fpgpu_ctx* ctx, const void* A, const void* B, void* C
     if (!ctx) return fail(FPGPU_ERR_SHAPE, "null context");
     if (workspace && (uintptr_t)workspace % 256) return fail(FPGPU_ERR_SHAPE, "matmul: workspace not 256-byte aligned");
     if (m == 0 || n == 0) return FPGPU_OK;
+    // one column: C = A B is the mat-vec y = A x with x = B, y = C (4096 x 4096 x 1: 12 G terms/s through the tiled
+    // kernel, the mat-vec kernels' rate through this)
+    if (n == 1) return fpgpu_matvec_dev(ctx, A, m, k, B, C, workspace, workspace_bytes, stream);
     CHECK(check_ptr(ctx, C, "C"));
     if (k != 0) {
         CHECK(check_ptr(ctx, A, "A"));

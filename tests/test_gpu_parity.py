@@ -437,8 +437,8 @@ def _dev_matmul(cpa, f, A, B, m, k, n, use_ws):
     ws = None
     if use_ws:
         nb = f.matmul_workspace_bytes(m, k, n)
-        assert nb > 0
-        ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+        assert nb > 0 or n == 1                          # one column: the mat-vec's workspace, 0 for a tiny one
+        ws = torch.empty(max(nb, 256), dtype=torch.uint8, device="cuda")
     f.matmul_dev(dA, dB, dC, m, k, n, workspace=ws)
     torch.cuda.synchronize()
     return dC.cpu().numpy().view(np.uint64)
@@ -745,6 +745,37 @@ def test_matvec_few_long_rows_split_over_columns(cpa, name, p, n64, rows, cols):
     assert np.array_equal(_dev_matvec(cpa, f, A, rows, cols, x, True).reshape(want.shape), want), "column parts"
     assert np.array_equal(_dev_matvec(cpa, f, A, rows, cols, x, False).reshape(want.shape), want), "whole rows"
     assert np.array_equal(f.matvec(A, rows, cols, x), want), "host call"
+
+
+@pytest.mark.parametrize("name,p,n64", [("bn254", 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001, 4),
+                                        ("bls12_381", 0x1A0111EA397FE69A4B1BA7B6434BACD764774B84F38512BF6730D2A0F6B0F6241EABFFFEB153FFFFB9FEFFFFFFFFAAAB, 6),
+                                        ("goldilocks", 2**64 - 2**32 + 1, 1), ("p512", 2**512 - 569, 8), ("p192", 2**192 - 2**64 - 1, 3)])
+def test_matmul_small_outputs_over_a_long_k_and_single_columns(cpa, name, p, n64):
+    """Shapes whose 16 x 16 output tiles cannot fill the chip: with the scratch fpgpu_matmul_workspace_bytes reports for
+    them, k is split over many workgroups per tile (ragged last part) and the partial residues are added per output;
+    a product with ONE column is handed to the mat-vec kernels (with and without their workspace).  Oracle, bit for bit."""
+    from oracle.fp_oracle import Oracle
+    from soak_inversion_plans import rand_elems
+    f, o = cpa.MontyField(p, n64), Oracle(p, n64)
+    rng = np.random.default_rng(n64 + 40)
+    for m, k, n in ((16, 5000, 16), (3, 8200, 5), (40, 4100, 33), (1, 70001, 2)):
+        A, B = rand_elems(rng, m * k, n64, p), rand_elems(rng, k * n, n64, p)
+        A[:2], B[:2] = ints_to_array([p - 1, 0], n64), ints_to_array([p - 1, 1], n64)
+        want = o.matmul(A, B, m, k, n, threads=0)
+        assert f.matmul_workspace_bytes(m, k, n) >= 2 * m * n * 8 * n64, (m, k, n)
+        assert np.array_equal(_dev_matmul(cpa, f, A, B, m, k, n, True).reshape(want.shape), want), ("k parts", m, k, n)
+        assert np.array_equal(_dev_matmul(cpa, f, A, B, m, k, n, False).reshape(want.shape), want), ("whole k", m, k, n)
+        assert np.array_equal(f.matmul(A, B, m, k, n), want), ("host call", m, k, n)
+    for m, k in ((300, 700), (70003, 5), (2, 300001), (33, 1)):
+        A, B = rand_elems(rng, m * k, n64, p), rand_elems(rng, k, n64, p)
+        want = o.matmul(A, B, m, k, 1, threads=0)
+        assert np.array_equal(want, o.matvec(A, m, k, B, threads=0))
+        use_ws = f.matmul_workspace_bytes(m, k, 1) > 0
+        assert f.matmul_workspace_bytes(m, k, 1) == f.matvec_workspace_bytes(m, k)
+        if use_ws:
+            assert np.array_equal(_dev_matmul(cpa, f, A, B, m, k, 1, True).reshape(want.shape), want), ("one column, workspace", m, k)
+        assert np.array_equal(_dev_matmul(cpa, f, A, B, m, k, 1, False).reshape(want.shape), want), ("one column", m, k)
+        assert np.array_equal(f.matmul(A, B, m, k, 1), want)
 
 
 _MV_VALU_MODULI = _UNSAT_MODULI + [("goldilocks", 2**64 - 2**32 + 1, 1), ("p61 in one word", 2**61 - 1, 1), ("p128 h=1", 2**127 - 1, 2),
