@@ -217,7 +217,11 @@ int fpgpu_spmv_dev(const fpgpu_ctx *ctx, const void *vals, const uint32_t *col_i
  * `workspace` is optional device scratch (256-byte aligned) of at least
  * fpgpu_matmul_workspace_bytes(ctx, m, k, n) bytes; with it, single-limb fields (n64 == 1,
  * k <= 16320) run on the matrix cores (int8 digit planes of A and B^T live there).  Without
- * it (NULL), or where that size is 0, the VALU kernels run.  Results are identical. */
+ * it (NULL), or where that size is 0, the VALU kernels run.  Results are identical.  Two shapes
+ * use the workspace at every width: a small output over a long k (at most 128 tiles of 16 x 16,
+ * k >= 4096) splits k over workgroups through it -- without it such a product runs on a few
+ * workgroups (16 x 2^20 x 16: 335 ms against 1.0) -- and a product with one column (n == 1) is
+ * the mat-vec y = A x and takes the mat-vec's workspace (the size reported is that one). */
 size_t fpgpu_matmul_workspace_bytes(const fpgpu_ctx *ctx, size_t m, size_t k, size_t n);
 int fpgpu_matmul_dev(const fpgpu_ctx *ctx, const void *A, const void *B, void *C, size_t m, size_t k,
                      size_t n, void *workspace, size_t workspace_bytes, void *stream);
