@@ -56,6 +56,13 @@ def main():
         # ---- mat-vec: rows x cols up to 2^22 elements, shapes from tall to wide
         cols = rnd.choice([rnd.randint(1, 64), rnd.randint(64, 2048), rnd.randint(2048, 40000)])
         rows = rnd.randint(1, max(1, min(3000, (1 << 22) // cols)))
+        kind = rnd.random()
+        if kind < 0.15:        # tall and narrow: one row per lane
+            cols = rnd.randint(1, 40)
+            rows = rnd.randint(65536, 110000)
+        elif kind < 0.3:       # a few rows longer than the matrix-core plan takes: column parts through the workspace
+            cols = ((1 << 23) // (8 * n64)) + rnd.randint(1, 50000)
+            rows = rnd.randint(1, 6)
         A, x = spiced(rng, rnd, rows * cols, n64, p), spiced(rng, rnd, cols, n64, p)
         want = o.matvec(A, rows, cols, x, threads=0)
         dA, dx = dev(A), dev(x)
@@ -68,14 +75,19 @@ def main():
                  and np.array_equal(y_v.cpu().numpy().view(np.uint64).reshape(rows, n64), want))
         # ---- mat-mul: m x k x n up to 2^25 terms (host call: matrix cores for single-limb fields, VALU kernels otherwise)
         m, k, n = rnd.randint(1, 400), rnd.choice([rnd.randint(1, 70), rnd.randint(70, 1200)]), rnd.randint(1, 400)
+        if rnd.random() < 0.25:   # a small output over a long k (k parts through the workspace), now and then one column
+            m, k, n = rnd.randint(1, 40), rnd.randint(4096, 30000), rnd.choice([1, rnd.randint(1, 40)])
         while m * k * n > (1 << 25):
             k = max(1, k // 2)
         Am, Bm = spiced(rng, rnd, m * k, n64, p), spiced(rng, rnd, k * n, n64, p)
         wantm = o.matmul(Am, Bm, m, k, n, threads=0)
-        C = f.alloc(m * n)
-        f.matmul_dev(dev(Am), dev(Bm), C, m, k, n)                      # no workspace: VALU kernels
+        C, C2 = f.alloc(m * n), f.alloc(m * n)
+        f.matmul_dev(dev(Am), dev(Bm), C, m, k, n)                      # no workspace: VALU kernels, whole k
+        wsm = torch.empty(max(256, f.matmul_workspace_bytes(m, k, n)), dtype=torch.uint8, device="cuda")
+        f.matmul_dev(dev(Am), dev(Bm), C2, m, k, n, workspace=wsm)      # matrix cores / k parts / the mat-vec kernels, as the shape has it
         torch.cuda.synchronize()
-        ok_mm = np.array_equal(f.matmul(Am, Bm, m, k, n), wantm) and np.array_equal(C.cpu().numpy().view(np.uint64).reshape(m * n, n64), wantm)
+        ok_mm = (np.array_equal(f.matmul(Am, Bm, m, k, n), wantm) and np.array_equal(C.cpu().numpy().view(np.uint64).reshape(m * n, n64), wantm)
+                 and np.array_equal(C2.cpu().numpy().view(np.uint64).reshape(m * n, n64), wantm))
         cases += 1
         print(json.dumps({"case": cases, "n64": n64, "bits": bits, "matvec": [rows, cols], "matmul": [m, k, n],
                           "ok": bool(ok_mv and ok_mm), "p": hex(p)}), flush=True)
