@@ -73,6 +73,8 @@ hipError_t Launch<N>::batch_inv(const fpgpu_ctx* ctx, const void* x, void* out, 
     // level-0 prefixes as limbs in their own array when the caller's workspace has room for it
     const bool lp = p.bytes_lp != 0 && ws_bytes >= p.bytes_lp && tuning().inv_lp != 0;
     uint32_t* praw = lp ? (uint32_t*)(ws + p.lp_off) : nullptr;
+    // sparse level-0 prefixes where memory binds the sweeps: up to 256 bits, batches large enough for a second level
+    const bool sp = !lp && (tuning().inv_sp >= 0 ? tuning().inv_sp == 1 : (N <= 8 && p.levels >= 2));
     if (hipError_t e = hipMemsetAsync(any_poisoned, 0, sizeof(uint32_t), s); e != hipSuccess) return e;
     // the last stored level and the exact inversions share one kernel when that level's chains are short
     const bool fused = p.fused_top && tuning().inv_fuse_top != 0;
@@ -84,6 +86,9 @@ hipError_t Launch<N>::batch_inv(const fpgpu_ctx* ctx, const void* x, void* out, 
         if (l == 0 && lp)
             hipLaunchKernelGGL((k_binv_up<N, true, true>), dim3(blocks), dim3(kBlock), 0, s, X(0), O(0), praw, totals,
                                flags, p.count[0], p.c[0], P);
+        else if (l == 0 && sp)
+            hipLaunchKernelGGL((k_binv_up_sp<N>), dim3(blocks), dim3(kBlock), 0, s, X(0), O(0), totals, flags, p.count[0],
+                               p.c[0], P);
         else if (l == 0)
             hipLaunchKernelGGL((k_binv_up<N, true, false>), dim3(blocks), dim3(kBlock), 0, s, X(0), O(0),
                                (uint32_t*)nullptr, totals, flags, p.count[0], p.c[0], P);
@@ -113,6 +118,9 @@ hipError_t Launch<N>::batch_inv(const fpgpu_ctx* ctx, const void* x, void* out, 
         if (l == 0 && lp)
             hipLaunchKernelGGL((k_binv_down<N, true, true>), dim3(blocks), dim3(kBlock), 0, s, X(0), O(0),
                                (const uint32_t*)praw, inv_totals, p.count[0], p.c[0], P);
+        else if (l == 0 && sp)
+            hipLaunchKernelGGL((k_binv_down_sp<N>), dim3(blocks), dim3(kBlock), 0, s, X(0), O(0), inv_totals, p.count[0],
+                               p.c[0], P);
         else if (l == 0)
             hipLaunchKernelGGL((k_binv_down<N, true, false>), dim3(blocks), dim3(kBlock), 0, s, X(0), O(0),
                                (const uint32_t*)nullptr, inv_totals, p.count[0], p.c[0], P);

@@ -489,6 +489,126 @@ __global__ __launch_bounds__(kBlock) void k_binv_down(const uint32_t* __restrict
     store_elem<N>(out, first, w);
 }
 
+// ---- level 0 with SPARSE prefixes (large batches over fields of up to 256 bits, where memory binds the sweeps) ----
+// BN254: 2^24 elements move 160 bytes each through the two sweeps above (x, prefix out; prefix, x again, result) for
+// 3 multiplications of ~200 issue slots.  Here the up-sweep stores only every kInvSeg-th prefix of a chain, and the
+// down-sweep takes a chain in segments of kInvSeg elements: it loads the segment's elements (all in flight together)
+// and the one stored prefix, RE-MULTIPLIES the prefixes inside the segment, and walks the segment back.
+// 3 + (S - 1) / S multiplications per element instead of 3 for 64 - 64 / S bytes of prefix traffic less: 112 instead
+// of 160 bytes per element at S = 4.  Same results as the dense sweeps (a prefix is the same residue however it is
+// re-derived; what is written is canonical).  Measured (tools/exp_binv_sparse.py, 2^24 elements, dense -> sparse):
+// Goldilocks 0.141 -> 0.112 ms, 128 bits 0.290 -> 0.244, 192 bits 0.471 -> 0.432, BN254 0.641 -> 0.591; 320 bits
+// 0.906 -> 0.929 and up lose (arithmetic binds there), and so do batches small enough for a one-level plan
+// (3 M BN254 elements 0.145 -> 0.163): the launcher takes this path from 2 levels on and up to 256 bits.
+// (Loading the next segment before working on the current one costs a wave of occupancy and loses: 0.630.)
+constexpr int kInvSeg = 4;
+template <int N>
+__global__ __launch_bounds__(kBlock) void k_binv_up_sp(const uint32_t* __restrict__ x, uint32_t* __restrict__ prefix,
+                                                       uint32_t* __restrict__ totals, uint8_t* __restrict__ zero_flags,
+                                                       size_t n, const int C, const FpParams<N> P) {
+    const size_t M = (n + C - 1) / C;
+    const size_t chain = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    size_t e = chain;
+    if (chain >= M) return;
+    Chain<N> run(P);
+    uint32_t w[N], v[N], vn[N];
+    load_elem<N>(v, x, e);
+    {
+        const bool more = 1 < C && e + M < n;
+        load_elem<N>(vn, x, more ? e + M : e);
+        const bool z = is_zero<N>(v);
+        if (zero_flags) zero_flags[e] = z ? 1 : 0;
+#pragma unroll
+        for (int l = 0; l < N; l++) v[l] = z ? P.one[l] : v[l];
+        run.set(v);
+#pragma unroll
+        for (int l = 0; l < N; l++) v[l] = vn[l];
+        e += M;
+    }
+#pragma unroll 1
+    for (int k = 1; k < C && e < n; k++, e += M) {
+        const bool more = k + 1 < C && e + M < n;
+        load_elem<N>(vn, x, more ? e + M : e);
+        if (k % kInvSeg == 0) {   // the prefix a segment of the down-sweep starts from
+            run.get_words(w);
+            store_elem<N>(prefix, e, w);
+        }
+        const bool z = is_zero<N>(v);
+        if (zero_flags) zero_flags[e] = z ? 1 : 0;
+        if (!z) run.mulr(v);
+#pragma unroll
+        for (int l = 0; l < N; l++) v[l] = vn[l];
+    }
+    run.get_words(w);
+    store_elem<N>(totals, chain, w);
+}
+template <int N>
+__global__ __launch_bounds__(kBlock) void k_binv_down_sp(const uint32_t* __restrict__ x, uint32_t* __restrict__ out,
+                                                         const uint32_t* __restrict__ inv_totals, size_t n, const int C,
+                                                         const FpParams<N> P) {
+    constexpr int S = kInvSeg;
+    const size_t M = (n + C - 1) / C;
+    const size_t chain = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    const size_t first = chain;
+    if (chain >= M) return;
+    const size_t cnt = (n - first + M - 1) / M;
+    Chain<N> run(P), fw(P);
+    uint32_t w[N], xs[S][N], pre[S][N];
+    load_elem<N>(w, inv_totals, chain);
+    run.set(w);
+#pragma unroll 1
+    for (size_t kb = ((cnt - 1) / S) * S;; kb -= S) {
+        const int len = (int)(cnt - kb < (size_t)S ? cnt - kb : (size_t)S);
+        // the segment's elements and its stored prefix: up to S + 1 loads in flight (slots past the end re-read the first)
+#pragma unroll
+        for (int j = 0; j < S; j++) load_elem<N>(xs[j], x, first + (kb + (j < len ? j : 0)) * M);
+        if (kb > 0) load_elem<N>(pre[0], out, first + kb * M);   // the exclusive prefix k_binv_up_sp left in the output slot
+        // forward: pre[j] = product of the chain's elements before kb + j (zeros as units)
+#pragma unroll
+        for (int j = 0; j + 1 < S; j++) {
+            if (j + 1 < len) {
+                const bool z = is_zero<N>(xs[j]);
+                if (kb == 0 && j == 0) {
+                    uint32_t v0[N];
+#pragma unroll
+                    for (int l = 0; l < N; l++) v0[l] = z ? P.one[l] : xs[0][l];
+                    fw.set(v0);
+                } else {
+                    if (j == 0) fw.set(pre[0]);
+                    if (!z) fw.mulr(xs[j]);
+                }
+                fw.get_words(pre[j + 1]);
+            }
+        }
+        // backward
+#pragma unroll
+        for (int j = S - 1; j >= 0; j--) {
+            if (j < len) {
+                const size_t k = kb + j;
+                const bool z = is_zero<N>(xs[j]);
+                if (k == 0) {   // the first element of the chain: what is left of the running inverse is its inverse
+                    if (z) {
+#pragma unroll
+                        for (int l = 0; l < N; l++) w[l] = 0;
+                    } else {
+                        run.get_canonical(w);
+                    }
+                    store_elem<N>(out, first, w);
+                } else if (z) {
+#pragma unroll
+                    for (int l = 0; l < N; l++) w[l] = 0;
+                    store_elem<N>(out, first + k * M, w);
+                } else {
+                    run.mulr_to(w, pre[j]);
+                    store_elem<N>(out, first + k * M, w);
+                    run.mulr(xs[j]);
+                }
+            }
+        }
+        if (kb == 0) break;
+    }
+}
+
 // The last stored level and the exact inversions in ONE kernel (no separate up- and down-sweep over the
 // totals, no prefixes through HBM): lane c multiplies its chain {c + k M : k < cnt <= C} of the level's
 // elements together, keeping the running products in LDS (raw form, one column per lane, no barrier),

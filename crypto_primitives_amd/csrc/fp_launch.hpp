@@ -171,6 +171,7 @@ struct Tuning {
     long matvec_mfma = -1;    // FPGPU_MATVEC_MFMA: 0 forces the VALU mat-vec
     long matvec_ksplit = 0;   // FPGPU_MATVEC_KSPLIT: column parts per row block (matrix-core mat-vec)
     long matvec_t = 0;        // FPGPU_MATVEC_T: products per pass of the VALU mat-vec
+    long inv_sp = -1;         // FPGPU_INV_SP: 0 = dense level-0 prefixes at every width, 1 = sparse prefixes (k_binv_*_sp) wherever the limb form is not in use
     long matvec_rows = -1;    // FPGPU_MATVEC_ROWS: 1 = one row per lane (k_matvec_rows) whatever the shape, 0 = never; -1 = tall narrow matrices
     long matvec_cols = -1;    // FPGPU_MATVEC_COLS: 1 = VALU mat-vec on unsaturated column sums (k_matvec_cols), 0 = k_matvec; -1 = the launcher's choice
     long matmul_mfma = -1;    // FPGPU_MATMUL_MFMA: 0 forces the VALU single-limb mat-mul

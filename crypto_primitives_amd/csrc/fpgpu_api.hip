@@ -112,7 +112,7 @@ static const TuningEntry kTuningEntries[] = {
     {"FPGPU_POW_WINDOW", &Tuning::pow_window},         {"FPGPU_SPMV_UNROLL", &Tuning::spmv_unroll},
     {"FPGPU_INV_C0", &Tuning::inv_c0},                 {"FPGPU_INV_FUSE_TOP", &Tuning::inv_fuse_top},
     {"FPGPU_INV_LP", &Tuning::inv_lp},                 {"FPGPU_MATVEC_COLS", &Tuning::matvec_cols},
-    {"FPGPU_MATVEC_ROWS", &Tuning::matvec_rows},
+    {"FPGPU_MATVEC_ROWS", &Tuning::matvec_rows},        {"FPGPU_INV_SP", &Tuning::inv_sp},
 };
 static Tuning g_tuning_defaults;
 static Tuning g_tuning;

@@ -390,7 +390,7 @@ int fpgpu_vec_spmv(const fpgpu_ctx *ctx, const fpgpu_vec *vals, const fpgpu_idx 
 
 /* ---- tuning / test hooks -----------------------------------------------------
  * No counterpart in the reference.  The hooks of INTEGRATION.md section 4 (FPGPU_GRID_CAP,
- * FPGPU_INV_C, FPGPU_INV_C0, FPGPU_INV_FUSE_TOP, FPGPU_INV_LP, FPGPU_MATVEC_MFMA, FPGPU_MATVEC_KSPLIT, FPGPU_MATVEC_T, FPGPU_MATVEC_COLS, FPGPU_MATVEC_ROWS, FPGPU_MATMUL_MFMA,
+ * FPGPU_INV_C, FPGPU_INV_C0, FPGPU_INV_FUSE_TOP, FPGPU_INV_LP, FPGPU_INV_SP, FPGPU_MATVEC_MFMA, FPGPU_MATVEC_KSPLIT, FPGPU_MATVEC_T, FPGPU_MATVEC_COLS, FPGPU_MATVEC_ROWS, FPGPU_MATMUL_MFMA,
  * FPGPU_MATMUL_GENERIC, FPGPU_SPMV_LOG2G, FPGPU_SPMV_UNROLL, FPGPU_ALLGATHER_COPY, FPGPU_COPY_THREADS, FPGPU_POW_WINDOW) are read from the environment once, when the library
  * is first used; this call sets one afterwards (process-wide; FPGPU_TUNING_DEFAULT restores the
  * library's choice).  No hook changes a result -- they pick between bit-identical paths.  Not

@@ -1,6 +1,6 @@
 """Soak (not collected by pytest; run as `python tests/soak_inversion_plans.py [seconds] [seed]` on a GPU box):
 batch inversion, pow and the multiplication chain on RANDOM odd moduli of every width, with random tree plans
-(chain lengths per level, the fused top on / off, limb-form prefixes on / off), random lengths up to 2^18 and
+(chain lengths per level, the fused top on / off, limb-form prefixes on / off, sparse prefixes on / off), random lengths up to 2^18 and
 zeros / non-invertible elements sprinkled in, against the oracle bit for bit.  The suite's own tests pin seven
 hand-picked moduli for these paths; this looks for the modulus or the length nobody picked.  Prints one JSON line
 per case and a summary; exits non-zero at the first mismatch."""
@@ -49,7 +49,7 @@ def main():
     rng = np.random.default_rng(seed)
     t_end = time.time() + budget
     cases = 0
-    hooks = ("FPGPU_INV_C", "FPGPU_INV_C0", "FPGPU_INV_FUSE_TOP", "FPGPU_INV_LP")
+    hooks = ("FPGPU_INV_C", "FPGPU_INV_C0", "FPGPU_INV_FUSE_TOP", "FPGPU_INV_LP", "FPGPU_INV_SP")
     print(json.dumps({"soak": "inversion plans", "seed": seed, "seconds": budget}), flush=True)
     while time.time() < t_end:
         n64 = rnd.randint(1, 8)
@@ -68,6 +68,7 @@ def main():
             plan["FPGPU_INV_C0"] = rnd.choice([2, 4, 8, 16, 32, 64])
         plan["FPGPU_INV_FUSE_TOP"] = rnd.choice([None, 0, 1])
         plan["FPGPU_INV_LP"] = rnd.choice([None, 0, 1])
+        plan["FPGPU_INV_SP"] = rnd.choice([None, 0, 1, 1])   # sparse level-0 prefixes wherever the limb form is not in use
         fast = rnd.random() < 0.6
         for h, v in plan.items():
             _lib.tuning_set(h) if v is None else _lib.tuning_set(h, v)

@@ -977,6 +977,52 @@ def test_batch_inv_every_path_of_the_round3_kernels(cpa, tuning, name, p, n64, f
         assert f.inv_workspace_bytes(1 << 20, fast=True) > f.inv_workspace_bytes(1 << 20) + (1 << 20) * 8 * n64
 
 
+@pytest.mark.parametrize("name,p,n64", [("goldilocks", 2**64 - 2**32 + 1, 1), ("p127 in two words", 2**127 - 1, 2), ("p192 tight", 2**192 - 2**64 - 1, 3),
+                                        ("bn254", 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001, 4),
+                                        ("secp256k1 (tight)", 2**256 - 2**32 - 977, 4), ("p320", 2**320 - 197, 5),
+                                        ("bls12_381", 0x1A0111EA397FE69A4B1BA7B6434BACD764774B84F38512BF6730D2A0F6B0F6241EABFFFEB153FFFFB9FEFFFFFFFFAAAB, 6),
+                                        ("odd composite 128", 3 * (2**125 - 2**63 + 5) | 1, 2)])
+@pytest.mark.parametrize("c0", [2, 3, 4, 5, 9, 32])
+def test_batch_inv_sparse_prefixes(cpa, tuning, name, p, n64, c0):
+    """k_binv_up_sp / k_binv_down_sp (round 3): only every fourth prefix of a level-0 chain is stored, the down-sweep
+    re-multiplies the others segment by segment.  Forced with FPGPU_INV_SP = 1 at every width the minimum workspace
+    serves, chain lengths below, at and above the segment length (2, 3, 4, 5, 9, 32), lengths that leave ragged
+    chains and ragged last segments, zeros at the start, at segment boundaries and inside segments, whole chains of
+    zeros; against the oracle bit for bit, and against the dense sweeps."""
+    import torch
+    from oracle.fp_oracle import Oracle
+    tuning("FPGPU_INV_SP", 1)
+    tuning("FPGPU_INV_C0", c0)
+    tuning("FPGPU_INV_C", 4)
+    f, o = cpa.MontyField(p, n64), Oracle(p, n64)
+    rnd = random.Random(n64 * 100 + c0)
+    for n in (1, 2, 3, 4, 5, 7, 8, 9, 17, 4097, 20011):
+        m = (n + c0 - 1) // c0                     # chains at level 0: chain c = {c + k m}
+        xs = [rnd.randrange(1, p) for _ in range(n)]
+        for i in range(0, n, 211):
+            xs[i] = 0
+        xs[0] = 0                                  # the first element of chain 0
+        for k in (3, 4, 5):                        # around the first segment boundary of chain 1
+            if k * m + 1 < n:
+                xs[k * m + 1] = 0
+        if 2 < m:
+            for k in range(0, n - 2, m):           # chain 2: nothing but zeros
+                xs[k + 2] = 0
+        xs[-1] = 0
+        if "composite" in name and n > 100:
+            xs[50], xs[n // 2] = 3, 9
+        x = ints_to_array(xs, n64)
+        want, wflags = o.batch_inv(x)
+        dx = torch.from_numpy(x.view(np.int64)).cuda()
+        out = f.alloc(n)
+        flags = torch.empty(n, dtype=torch.uint8, device="cuda")
+        ws = torch.empty(f.inv_workspace_bytes(n), dtype=torch.uint8, device="cuda")   # the minimum: no limb-form prefixes
+        f.inv_dev(dx, out, flags, ws)
+        torch.cuda.synchronize()
+        assert np.array_equal(flags.cpu().numpy(), wflags), (n, "flags")
+        assert np.array_equal(out.cpu().numpy().view(np.uint64).reshape(n, n64), want), n
+
+
 def test_device_wrappers_validate_shapes(cpa):
     """The Python device wrappers refuse operands whose element counts do not match what the kernel
     will touch (a short `out` would otherwise be written past its end)."""
