@@ -160,7 +160,7 @@ hipError_t Launch<N>::matvec(const fpgpu_ctx* ctx, const void* A, size_t rows, s
         const size_t widest = cores ? (N == 8 ? 128 : 64) : (N >= 8 ? 512 : 256);
         if (tune.matvec_rows >= 0 ? tune.matvec_rows == 1 : (cols <= widest && rows >= kMvRowsMinRows)) {
             hipLaunchKernelGGL((k_matvec_rows<N>), dim3(grid_for(rows)), dim3(kBlock), 0, s, (const uint32_t*)A, (const uint32_t*)x,
-                               (uint32_t*)y, rows, cols, make_params<N>(ctx));
+                               (uint32_t*)y, rows, cols, make_params<N>(ctx), cols, (size_t)1, 1u, cols);
             return hipSuccess;
         }
         if (cores) {
@@ -239,6 +239,26 @@ hipError_t Launch<N>::matvec(const fpgpu_ctx* ctx, const void* A, size_t rows, s
 template <int N>
 hipError_t Launch<N>::matmul(const fpgpu_ctx* ctx, const void* A, const void* B, void* C, size_t m, size_t k, size_t n,
                        void* workspace, size_t workspace_bytes, hipStream_t s) {
+    // a few vectors times a matrix: one lane per output column, B streamed once per vector, as it lies
+    if (vm_shape(m, k, n)) {
+        uint32_t parts = vm_split_parts(k, n);
+        if (parts > 1 && !(workspace && workspace_bytes >= vm_split_bytes(ctx->n64, k, n))) parts = 1;
+        if (parts > 1 || n >= 16384) {
+            const size_t per = parts > 1 ? (k + parts - 1) / parts : k;
+            for (size_t i = 0; i < m; i++) {
+                uint32_t* dst = (uint32_t*)C + i * n * N;
+                hipLaunchKernelGGL((k_matvec_rows<N>), dim3(grid_for(n * parts)), dim3(kBlock), 0, s, (const uint32_t*)B,
+                                   (const uint32_t*)A + i * k * N, parts > 1 ? (uint32_t*)workspace : dst, n, k, make_params<N>(ctx),
+                                   (size_t)1, n, parts, per);
+                if (parts > 1) {
+                    const size_t cw = (n + kBlock / 64 - 1) / (kBlock / 64);
+                    hipLaunchKernelGGL((k_matvec_combine<N>), dim3((unsigned)cw), dim3(kBlock), 0, s, (const uint32_t*)workspace, dst, n,
+                                       parts, make_params<N>(ctx));
+                }
+            }
+            return hipSuccess;
+        }
+    }
     // a small output over a long k, with the scratch for it: k split over workgroups (every width, the multi-limb kernel)
     if (const uint32_t parts = mm_split_parts(m, k, n);
         parts > 1 && workspace && workspace_bytes >= mm_split_bytes(ctx->n64, m, k, n) ) {

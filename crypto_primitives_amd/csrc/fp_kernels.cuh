@@ -901,12 +901,23 @@ __global__ __launch_bounds__(kBlock) void k_matvec_cols(const uint32_t* __restri
 // and the 64 rows of a wave are one contiguous piece of the matrix.
 template <int N>
 __global__ __launch_bounds__(kBlock) void k_matvec_rows(const uint32_t* __restrict__ A, const uint32_t* __restrict__ x,
-                                                        uint32_t* __restrict__ y, size_t rows, size_t cols, const FpParams<N> P) {
+                                                        uint32_t* __restrict__ y, size_t rows, size_t cols, const FpParams<N> P,
+                                                        size_t row_stride, size_t col_stride, uint32_t parts, size_t per_part) {
+    // Element (row, j) of the matrix is A[row * row_stride + j * col_stride] (in elements): (cols, 1) for y = A x; (1, n)
+    // for a VECTOR TIMES A MATRIX, c = a B with B k x n row-major -- then "row" is an output column, consecutive lanes
+    // read consecutive elements of one row of B, and x[j] = a[j] is still a scalar load.  parts > 1 (few outputs over
+    // many terms): item = part * rows + row takes terms [part * per_part, (part + 1) * per_part) and writes its partial
+    // residue to y[row * parts + part] -- the launcher's scratch, summed per row by k_matvec_combine.
     constexpr int L = UF<N>::L, NC = 2 * L + 2, TT = 63 / L, U = N <= 8 ? 4 : 2;
     constexpr uint32_t M = UF<N>::C::MASK;
     const size_t stride = (size_t)gridDim.x * kBlock;
-    for (size_t row = (size_t)blockIdx.x * kBlock + threadIdx.x; row < rows; row += stride) {
-        const uint32_t* __restrict__ Arow = A + row * cols * N;
+    const size_t items = rows * parts;
+    for (size_t item = (size_t)blockIdx.x * kBlock + threadIdx.x; item < items; item += stride) {
+        // (parts are the slow index: consecutive lanes stay on consecutive rows, i.e. on consecutive elements of B)
+        const size_t row = parts > 1 ? item % rows : item;
+        const size_t jb = parts > 1 ? (item / rows) * per_part : 0;
+        const size_t je = parts > 1 && jb + per_part < cols ? jb + per_part : cols;
+        const uint32_t* __restrict__ Arow = A + row * row_stride * N;
         uint64_t c[NC];
 #pragma unroll
         for (int i = 0; i < NC; i++) c[i] = 0;
@@ -932,17 +943,17 @@ __global__ __launch_bounds__(kBlock) void k_matvec_rows(const uint32_t* __restri
                 pending = 0;
             }
         };
-        size_t j = 0;
-        for (; j + U <= cols; j += U) {
+        size_t j = jb;
+        for (; j + U <= je; j += U) {
             uint32_t va[U][N];
 #pragma unroll
-            for (int u = 0; u < U; u++) load_elem<N>(va[u], Arow, j + u);
+            for (int u = 0; u < U; u++) load_elem<N>(va[u], Arow, (j + u) * col_stride);
 #pragma unroll
             for (int u = 0; u < U; u++) term(va[u], j + u);
         }
-        for (; j < cols; j++) {
+        for (; j < je; j++) {
             uint32_t va[N];
-            load_elem<N>(va, Arow, j);
+            load_elem<N>(va, Arow, j * col_stride);
             term(va, j);
         }
         normalise();
@@ -961,7 +972,7 @@ __global__ __launch_bounds__(kBlock) void k_matvec_rows(const uint32_t* __restri
         mont_mul<N>(t2, w2, r2, P);
         mod_add<N>(s, t0, t1, P);
         mod_add<N>(acc, s, t2, P);
-        store_elem<N>(y, row, acc);
+        store_elem<N>(y, parts > 1 ? row * parts + item / rows : item, acc);
     }
 }
 

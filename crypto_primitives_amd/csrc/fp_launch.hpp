@@ -136,6 +136,23 @@ inline size_t mm_split_bytes(uint32_t n64, size_t m, size_t k, size_t n) {
     const uint32_t parts = mm_split_parts(m, k, n);
     return parts < 2 ? 0 : ((m * n * parts * 8 * (size_t)n64 + 255) / 256) * 256;
 }
+// A few vectors times a matrix (m <= 4 rows of A against B k x n: random linear combinations of k rows): one lane per
+// output column (k_matvec_rows with B's strides); when the columns are too few for that, the k terms are split over
+// `parts` lanes per column through the workspace.
+constexpr size_t kVmMaxRows = 4, kVmMinCols = 1024;
+inline uint32_t vm_split_parts(size_t k, size_t n) {
+    constexpr size_t kLanesWanted = 262144;   // four waves per SIMD
+    if (n == 0 || n >= kLanesWanted || k < 128) return 1;
+    size_t parts = (kLanesWanted + n - 1) / n;
+    const size_t most = k / 64;
+    if (parts > most) parts = most;
+    return parts < 2 ? 1 : (uint32_t)parts;
+}
+inline size_t vm_split_bytes(uint32_t n64, size_t k, size_t n) {
+    const uint32_t parts = vm_split_parts(k, n);
+    return parts < 2 ? 0 : ((n * parts * 8 * (size_t)n64 + 255) / 256) * 256;
+}
+inline bool vm_shape(size_t m, size_t k, size_t n) { return m >= 1 && m <= kVmMaxRows && n >= kVmMinCols && k >= 1; }
 // Workspace of the matrix-core mat-mul (fp_matmul_mfma.cuh): a flag word, then the int8 digit
 // planes of A and of B^T in 64-row blocks x 64-deep k-steps x 32 KiB.
 struct MfmaPlan {

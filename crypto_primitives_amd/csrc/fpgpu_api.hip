@@ -456,6 +456,10 @@ int fpgpu_spmv_dev(const fpgpu_ctx* ctx, const void* vals, const uint32_t* col_i
 size_t fpgpu_matmul_workspace_bytes(const fpgpu_ctx* ctx, size_t m, size_t k, size_t n) {
     if (!ctx) return 0;
     if (n == 1) return fpgpu_matvec_workspace_bytes(ctx, m, k);   // a mat-vec: served by its kernels
+    if (vm_shape(m, k, n)) {   // a few vectors times a matrix: k parts only when the columns alone cannot fill the chip
+        if (const size_t vm = vm_split_bytes(ctx->n64, k, n)) return vm;
+        if (n >= 16384) return 0;
+    }
     if (const size_t split = mm_split_bytes(ctx->n64, m, k, n)) return split;   // a small output over a long k: scratch for the k parts
     const MfmaPlan pl = make_mfma_plan(ctx->n64, m, k, n);
     return pl.usable ? pl.bytes : 0;

@@ -221,7 +221,9 @@ int fpgpu_spmv_dev(const fpgpu_ctx *ctx, const void *vals, const uint32_t *col_i
  * use the workspace at every width: a small output over a long k (at most 128 tiles of 16 x 16,
  * k >= 4096) splits k over workgroups through it -- without it such a product runs on a few
  * workgroups (16 x 2^20 x 16: 335 ms against 1.0) -- and a product with one column (n == 1) is
- * the mat-vec y = A x and takes the mat-vec's workspace (the size reported is that one). */
+ * the mat-vec y = A x and takes the mat-vec's workspace (the size reported is that one).  One to
+ * four vectors times a matrix (m <= 4, n >= 1024: linear combinations of the k rows of B) run a lane
+ * per output column and stream B once per vector; the workspace serves them when n < 2^18. */
 size_t fpgpu_matmul_workspace_bytes(const fpgpu_ctx *ctx, size_t m, size_t k, size_t n);
 int fpgpu_matmul_dev(const fpgpu_ctx *ctx, const void *A, const void *B, void *C, size_t m, size_t k,
                      size_t n, void *workspace, size_t workspace_bytes, void *stream);

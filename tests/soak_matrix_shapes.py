@@ -77,6 +77,8 @@ def main():
         m, k, n = rnd.randint(1, 400), rnd.choice([rnd.randint(1, 70), rnd.randint(70, 1200)]), rnd.randint(1, 400)
         if rnd.random() < 0.25:   # a small output over a long k (k parts through the workspace), now and then one column
             m, k, n = rnd.randint(1, 40), rnd.randint(4096, 30000), rnd.choice([1, rnd.randint(1, 40)])
+        elif rnd.random() < 0.2:  # a few vectors times a matrix: a lane per output column, k parts through the workspace
+            m, k, n = rnd.randint(1, 4), rnd.randint(1, 3000), rnd.randint(1024, 6000)
         while m * k * n > (1 << 25):
             k = max(1, k // 2)
         Am, Bm = spiced(rng, rnd, m * k, n64, p), spiced(rng, rnd, k * n, n64, p)

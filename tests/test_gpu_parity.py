@@ -766,6 +766,20 @@ def test_matmul_small_outputs_over_a_long_k_and_single_columns(cpa, name, p, n64
         assert np.array_equal(_dev_matmul(cpa, f, A, B, m, k, n, True).reshape(want.shape), want), ("k parts", m, k, n)
         assert np.array_equal(_dev_matmul(cpa, f, A, B, m, k, n, False).reshape(want.shape), want), ("whole k", m, k, n)
         assert np.array_equal(f.matmul(A, B, m, k, n), want), ("host call", m, k, n)
+    # a few vectors times a matrix: one lane per output column; k parts through the workspace when the columns are few
+    for m, k, n in ((1, 4099, 4096), (3, 700, 20000), (2, 100, 70001), (4, 5000, 1024), (1, 1, 1024), (2, 129, 1500)):
+        A, B = rand_elems(rng, m * k, n64, p), rand_elems(rng, k * n, n64, p)
+        A[:1], B[:2] = ints_to_array([p - 1], n64), ints_to_array([p - 1, 1], n64)
+        want = o.matmul(A, B, m, k, n, threads=0)
+        dC = _dev_matmul(cpa, f, A, B, m, k, n, False).reshape(want.shape)
+        assert np.array_equal(dC, want), ("vector times matrix", m, k, n)
+        nb = f.matmul_workspace_bytes(m, k, n)
+        import torch
+        ws = torch.empty(max(nb, 256), dtype=torch.uint8, device="cuda")
+        dA, dB, dC2 = torch.from_numpy(A.view(np.int64)).cuda(), torch.from_numpy(B.view(np.int64)).cuda(), f.alloc(m * n)
+        f.matmul_dev(dA, dB, dC2, m, k, n, workspace=ws)
+        torch.cuda.synchronize()
+        assert np.array_equal(dC2.cpu().numpy().view(np.uint64).reshape(want.shape), want), ("vector times matrix, workspace", m, k, n, nb)
     for m, k in ((300, 700), (70003, 5), (2, 300001), (33, 1)):
         A, B = rand_elems(rng, m * k, n64, p), rand_elems(rng, k, n64, p)
         want = o.matmul(A, B, m, k, 1, threads=0)

@@ -5,7 +5,7 @@ import torch
 import crypto_primitives_amd as cpa
 f = cpa.MontyField(cpa.BN254_FR, 4)
 for m, k, n in ((1024, 1024, 1024), (4096, 4096, 16), (16, 4096, 4096), (16, 1 << 20, 16), (64, 1 << 18, 64), (4096, 4096, 1), (1, 4096, 4096),
-                (256, 65536, 256), (1000, 1000, 1000), (2048, 64, 2048), (8192, 8, 8192)):
+                (256, 65536, 256), (1000, 1000, 1000), (2048, 64, 2048), (8192, 8, 8192), (1, 1 << 10, 1 << 20), (1, 1 << 16, 1 << 14), (4, 4096, 1 << 16), (1, 1 << 20, 1024)):
     A = f.random_dev(m * k, 1); B = f.random_dev(k * n, 2); C = f.alloc(m * n)
     wb = f.matmul_workspace_bytes(m, k, n)
     ws = torch.empty(wb, dtype=torch.uint8, device="cuda") if wb else None
