@@ -749,7 +749,7 @@ def test_matvec_few_long_rows_split_over_columns(cpa, name, p, n64, rows, cols):
 
 @pytest.mark.parametrize("name,p,n64", [("bn254", 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001, 4),
                                         ("bls12_381", 0x1A0111EA397FE69A4B1BA7B6434BACD764774B84F38512BF6730D2A0F6B0F6241EABFFFEB153FFFFB9FEFFFFFFFFAAAB, 6),
-                                        ("goldilocks", 2**64 - 2**32 + 1, 1), ("p512", 2**512 - 569, 8), ("p192", 2**192 - 2**64 - 1, 3)])
+                                        ("goldilocks", 2**64 - 2**32 + 1, 1), ("p512", 2**512 - 569, 8)])
 def test_matmul_small_outputs_over_a_long_k_and_single_columns(cpa, name, p, n64):
     """Shapes whose 16 x 16 output tiles cannot fill the chip: with the scratch fpgpu_matmul_workspace_bytes reports for
     them, k is split over many workgroups per tile (ragged last part) and the partial residues are added per output;
@@ -767,7 +767,7 @@ def test_matmul_small_outputs_over_a_long_k_and_single_columns(cpa, name, p, n64
         assert np.array_equal(_dev_matmul(cpa, f, A, B, m, k, n, False).reshape(want.shape), want), ("whole k", m, k, n)
         assert np.array_equal(f.matmul(A, B, m, k, n), want), ("host call", m, k, n)
     # a few vectors times a matrix: one lane per output column; k parts through the workspace when the columns are few
-    for m, k, n in ((1, 4099, 4096), (3, 700, 20000), (2, 100, 70001), (4, 5000, 1024), (1, 1, 1024), (2, 129, 1500)):
+    for m, k, n in ((1, 2051, 2048), (3, 300, 5000), (2, 40, 70001), (4, 1500, 1024), (1, 1, 1024), (2, 129, 1500)):
         A, B = rand_elems(rng, m * k, n64, p), rand_elems(rng, k * n, n64, p)
         A[:1], B[:2] = ints_to_array([p - 1], n64), ints_to_array([p - 1, 1], n64)
         want = o.matmul(A, B, m, k, n, threads=0)
@@ -963,7 +963,7 @@ def test_batch_inv_every_path_of_the_round3_kernels(cpa, tuning, name, p, n64, f
     tuning("FPGPU_INV_C", 4)                       # level 0: 8, above it: 4 (fused when fuse = 1)
     f, o = cpa.MontyField(p, n64), Oracle(p, n64)
     rnd = random.Random(n64 * 7 + fuse)
-    for n in (1, 7, 8, 9, 4097, 300007):
+    for n in (1, 7, 8, 9, 4097, 70001):
         m = (n + 7) // 8                          # chains at level 0: chain c = {c + k m}
         xs = [rnd.randrange(1, p) for _ in range(n)]
         for i in range(0, n, 1013):
