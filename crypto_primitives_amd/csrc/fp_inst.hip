@@ -3,6 +3,8 @@
 #include "fp_launch.hpp"
 #if FPGPU_N == 2
 #include "fp_matmul_mfma.cuh"
+#elif FPGPU_N >= 4
+#include "fp_matmul_mfma_limbs.cuh"
 #endif
 #include "fp_matvec_mfma.cuh"
 
@@ -265,7 +267,8 @@ hipError_t Launch<N>::matmul(const fpgpu_ctx* ctx, const void* A, const void* B,
         const size_t kper = ((k + parts - 1) / parts + kMMTile - 1) / kMMTile * kMMTile;
         const size_t gx = (n + kMMTile - 1) / kMMTile, gy = (m + kMMTile - 1) / kMMTile;
         hipLaunchKernelGGL((k_matmul<N>), dim3((unsigned)gx, (unsigned)gy, parts), dim3(kMMTile * kMMTile), 0, s,
-                           (const uint32_t*)A, (const uint32_t*)B, (uint32_t*)workspace, m, k, n, make_params<N>(ctx), parts, kper);
+                           (const uint32_t*)A, (const uint32_t*)B, (uint32_t*)workspace, m, k, n, make_params<N>(ctx), parts, kper,
+                           (const uint32_t*)nullptr);
         const size_t outs = m * n, cw = (outs + kBlock / 64 - 1) / (kBlock / 64);
         hipLaunchKernelGGL((k_matvec_combine<N>), dim3((unsigned)cw), dim3(kBlock), 0, s, (const uint32_t*)workspace, (uint32_t*)C,
                            outs, parts, make_params<N>(ctx));
@@ -304,11 +307,33 @@ hipError_t Launch<N>::matmul(const fpgpu_ctx* ctx, const void* A, const void* B,
         }
     }
 #endif
-    (void)workspace;
-    (void)workspace_bytes;
     size_t gx = (n + kMMTile - 1) / kMMTile, gy = (m + kMMTile - 1) / kMMTile;
+    const uint32_t* gate = nullptr;
+#if FPGPU_N >= 4
+    {
+        // multi-limb product on the matrix cores (fp_matmul_mfma_limbs.cuh) where the plan's cost model prefers it and
+        // the workspace holds its digit planes and scratch; the hook matmul_mfma = 0 keeps the VALU kernel, 1 takes the
+        // matrix cores for every shape the plan can lay out (parity tests on small shapes)
+        const Tuning& tune = tuning();
+        const MflPlan pl = make_mfl_plan(ctx->n64, m, k, n, tune.matmul_mfma > 0);
+        if (pl.usable && workspace && workspace_bytes >= pl.bytes && tune.matmul_mfma != 0 && tune.matmul_generic <= 0) {
+            uint8_t* ws = (uint8_t*)workspace;
+            uint32_t* flag = (uint32_t*)ws;
+            if (hipError_t e = hipMemsetAsync(flag, 0, 4, s); e != hipSuccess) return e;
+            const unsigned wa = pl.rblocks * pl.ksteps, wb = pl.cblocks * pl.ksteps;  // x4 waves = one workgroup each
+            hipLaunchKernelGGL((k_mfl_digitize<N, false>), dim3(wa), dim3(256), 0, s, (const uint32_t*)A, m, k, k,
+                               ws + pl.a_off, pl.plane_a, pl.rblocks, pl.ksteps, flag, make_params<N>(ctx));
+            hipLaunchKernelGGL((k_mfl_digitize<N, true>), dim3(wb), dim3(256), 0, s, (const uint32_t*)B, n, k, n,
+                               ws + pl.b_off, pl.plane_b, pl.cblocks, pl.ksteps, flag, make_params<N>(ctx));
+            hipLaunchKernelGGL((k_matmul_mfma_limbs<N>), dim3(pl.grid), dim3(256), 0, s, ws + pl.a_off, ws + pl.b_off,
+                               pl.plane_a, pl.plane_b, (uint32_t*)C, m, n, pl.rblocks, pl.cblocks, pl.ksteps,
+                               (uint32_t*)(ws + pl.t_off), (const uint32_t*)flag, make_params<N>(ctx));
+            gate = flag;   // the VALU kernel below then runs only if some input had no digit form
+        }
+    }
+#endif
     hipLaunchKernelGGL((k_matmul<N>), dim3((unsigned)gx, (unsigned)gy), dim3(kMMTile * kMMTile), 0, s,
-                       (const uint32_t*)A, (const uint32_t*)B, (uint32_t*)C, m, k, n, make_params<N>(ctx), 1u, k);
+                       (const uint32_t*)A, (const uint32_t*)B, (uint32_t*)C, m, k, n, make_params<N>(ctx), 1u, k, gate);
     return hipSuccess;
 }
 

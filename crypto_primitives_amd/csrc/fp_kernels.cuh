@@ -1082,7 +1082,10 @@ template <int N>
 __global__ __launch_bounds__(kMMTile* kMMTile) void k_matmul(const uint32_t* __restrict__ A,
                                                              const uint32_t* __restrict__ B,
                                                              uint32_t* __restrict__ Cm, size_t m, size_t k, size_t n,
-                                                             const FpParams<N> P, uint32_t kparts, size_t kper) {
+                                                             const FpParams<N> P, uint32_t kparts, size_t kper,
+                                                             const uint32_t* __restrict__ run_if_set) {
+    // as the fallback of k_matmul_mfma_limbs this runs only when the digitiser raised its flag
+    if (run_if_set && *run_if_set == 0) return;
     // kparts > 1 (a small output over a long k: too few tiles to fill the chip): blockIdx.z takes the terms
     // [z * kper, (z + 1) * kper) and writes the canonical residue of its partial sum to Cm[(row * n + col) * kparts + z]
     // -- Cm is then the launcher's scratch, and k_matvec_combine adds the parts of every output

@@ -172,6 +172,44 @@ inline MfmaPlan make_mfma_plan(uint32_t n64, size_t m, size_t k, size_t n) {
     pl.bytes = pl.b_off + (size_t)pl.cblocks * pl.ksteps * 32768;
     return pl;
 }
+// Workspace of the multi-limb matrix-core mat-mul (fp_matmul_mfma_limbs.cuh): a flag word, the digit planes of every limb of
+// A and of B^T (each limb a plane set in the single-limb layout), and (2 n64 - 1) x 6 words x 4096 outputs of scratch per
+// workgroup of a persistent grid.  `usable` also says that the matrix cores are expected to WIN: the VALU kernel runs
+// n64^2 x 0.21 ps per term on the whole chip (296 G terms/s at 256 bits), a workgroup here n64^2 x 3.0 us per 64-deep
+// k-step of a 64 x 64 tile on ONE CU, so the tiles must come near the CUs' number and k must amortise the launches.
+struct MflPlan {
+    bool usable;
+    uint32_t rblocks, cblocks, ksteps, grid;
+    size_t plane_a, plane_b, a_off, b_off, t_off, bytes;
+};
+inline MflPlan make_mfl_plan(uint32_t n64, size_t m, size_t k, size_t n, bool forced = false) {
+    MflPlan pl{};
+    if (n64 < 2 || n64 > 8 || m == 0 || n == 0 || k == 0) return pl;
+    const size_t rb = (m + 63) / 64, cb = (n + 63) / 64, ks = (k + 63) / 64;
+    if (rb * cb >= (1u << 28) || ks >= (1u << 24)) return pl;
+    if (!forced) {
+        const double nl2 = (double)n64 * n64;
+        const double valu_us = (double)m * n * k * nl2 * 0.21e-6;
+        const double rounds = (double)((rb * cb + 255) / 256);
+        // measured (tools/exp_matmul_limbs.py, 256 ... 4096 on a side, 128 to 512 bits): 3.0 us per pair and k-step of a tile
+        // with the epilogues and pipeline restarts of a limb diagonal in it, 3.25 ps x n64^2 per digitised element, 40 us of launches
+        const double mfma_us = rounds * ks * nl2 * 3.0 + (double)(m + n) * k * nl2 * 3.25e-6 + 40.0;
+        if (mfma_us >= valu_us) return pl;
+    }
+    pl.usable = true;
+    pl.rblocks = (uint32_t)rb;
+    pl.cblocks = (uint32_t)cb;
+    pl.ksteps = (uint32_t)ks;
+    const size_t tiles8 = (rb * cb + 7) / 8 * 8;
+    pl.grid = (uint32_t)(tiles8 < 256 ? tiles8 : 256);
+    pl.plane_a = rb * ks * 32768;
+    pl.plane_b = cb * ks * 32768;
+    pl.a_off = 256;
+    pl.b_off = pl.a_off + n64 * pl.plane_a;
+    pl.t_off = pl.b_off + n64 * pl.plane_b;
+    pl.bytes = pl.t_off + (size_t)pl.grid * (2 * n64 - 1) * 6 * 4096 * 4;
+    return pl;
+}
 constexpr int kFoldBlocks = 2048;  // partials of the first fold pass (workspace = kFoldBlocks elements)
 int grid_for(size_t n);
 
@@ -191,7 +229,7 @@ struct Tuning {
     long inv_sp = -1;         // FPGPU_INV_SP: 0 = dense level-0 prefixes at every width, 1 = sparse prefixes (k_binv_*_sp) wherever the limb form is not in use
     long matvec_rows = -1;    // FPGPU_MATVEC_ROWS: 1 = one row per lane (k_matvec_rows) whatever the shape, 0 = never; -1 = tall narrow matrices
     long matvec_cols = -1;    // FPGPU_MATVEC_COLS: 1 = VALU mat-vec on unsaturated column sums (k_matvec_cols), 0 = k_matvec; -1 = the launcher's choice
-    long matmul_mfma = -1;    // FPGPU_MATMUL_MFMA: 0 forces the VALU single-limb mat-mul
+    long matmul_mfma = -1;    // FPGPU_MATMUL_MFMA: 0 forces the VALU mat-mul kernels; 1 takes the matrix cores for every multi-limb shape they can lay out, not only where they are expected to win
     long matmul_generic = 0;  // FPGPU_MATMUL_GENERIC: 1 forces the multi-limb mat-mul kernel
     long spmv_log2g = -1;     // FPGPU_SPMV_LOG2G: log2 of the lanes sharing a sparse row
     long spmv_unroll = 0;     // FPGPU_SPMV_UNROLL: cells a lane of the sparse mat-vec loads together (1, 2 or 4)

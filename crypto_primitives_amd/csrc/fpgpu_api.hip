@@ -461,6 +461,10 @@ size_t fpgpu_matmul_workspace_bytes(const fpgpu_ctx* ctx, size_t m, size_t k, si
         if (n >= 16384) return 0;
     }
     if (const size_t split = mm_split_bytes(ctx->n64, m, k, n)) return split;   // a small output over a long k: scratch for the k parts
+    if (ctx->n64 >= 2) {   // multi-limb: digit planes and scratch of the matrix-core product, where it is expected to win (or the hook asks)
+        const MflPlan ml = make_mfl_plan(ctx->n64, m, k, n, tuning().matmul_mfma > 0);
+        return ml.usable && tuning().matmul_mfma != 0 ? ml.bytes : 0;
+    }
     const MfmaPlan pl = make_mfma_plan(ctx->n64, m, k, n);
     return pl.usable ? pl.bytes : 0;
 }

@@ -18,6 +18,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import torch  # noqa: E402
 
 import crypto_primitives_amd as cpa  # noqa: E402
+from crypto_primitives_amd import _lib  # noqa: E402
 from oracle.fp_oracle import Oracle  # noqa: E402
 from soak_inversion_plans import rand_elems  # noqa: E402
 
@@ -81,6 +82,10 @@ def main():
             m, k, n = rnd.randint(1, 4), rnd.randint(1, 3000), rnd.randint(1024, 6000)
         while m * k * n > (1 << 25):
             k = max(1, k // 2)
+        # multi-limb products: now and then on the matrix cores whatever the shape (the plan alone takes them from ~64 tiles on)
+        force_mfma = n64 >= 2 and rnd.random() < 0.4
+        if force_mfma:
+            _lib.tuning_set("FPGPU_MATMUL_MFMA", 1)
         Am, Bm = spiced(rng, rnd, m * k, n64, p), spiced(rng, rnd, k * n, n64, p)
         wantm = o.matmul(Am, Bm, m, k, n, threads=0)
         C, C2 = f.alloc(m * n), f.alloc(m * n)
@@ -90,8 +95,9 @@ def main():
         torch.cuda.synchronize()
         ok_mm = (np.array_equal(f.matmul(Am, Bm, m, k, n), wantm) and np.array_equal(C.cpu().numpy().view(np.uint64).reshape(m * n, n64), wantm)
                  and np.array_equal(C2.cpu().numpy().view(np.uint64).reshape(m * n, n64), wantm))
+        _lib.tuning_set("FPGPU_MATMUL_MFMA")
         cases += 1
-        print(json.dumps({"case": cases, "n64": n64, "bits": bits, "matvec": [rows, cols], "matmul": [m, k, n],
+        print(json.dumps({"case": cases, "n64": n64, "bits": bits, "matvec": [rows, cols], "matmul": [m, k, n], "mfma_forced": force_mfma,
                           "ok": bool(ok_mv and ok_mm), "p": hex(p)}), flush=True)
         if not (ok_mv and ok_mm):
             print(json.dumps({"matvec_ok": bool(ok_mv), "matmul_ok": bool(ok_mm)}), flush=True)

@@ -504,6 +504,91 @@ def test_matmul_matrix_core_falls_back_on_undigitisable_inputs(cpa):
     assert np.array_equal(got2.reshape(-1), o.matmul(A2, B, m, k, n, threads=0).reshape(-1))
 
 
+_MFL_MODULI = [("bn254", 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001, 4),
+               ("bls12_381", 0x1A0111EA397FE69A4B1BA7B6434BACD764774B84F38512BF6730D2A0F6B0F6241EABFFFEB153FFFFB9FEFFFFFFFFAAAB, 6),
+               ("p127 in two words", 2**127 - 1, 2), ("p192", 2**192 - 2**64 - 1, 3), ("secp256k1 (tight)", 2**256 - 2**32 - 977, 4),
+               ("p320", 2**320 - 197, 5), ("p448", 2**448 - 2**224 - 1, 7), ("p512", 2**512 - 569, 8),
+               ("odd composite 384", 3 * (2**380 - 2**190 + 5) | 1, 6), ("120 bits in four words", 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFC7 , 4)]
+
+
+@pytest.mark.parametrize("case", _MFL_MODULI, ids=[c[0] for c in _MFL_MODULI])
+def test_matmul_multi_limb_matrix_core_path_vs_oracle(cpa, tuning, case):
+    """Multi-limb mat-mul as n64 x n64 single-limb products on the int8 matrix cores (fp_matmul_mfma_limbs.cuh), forced for
+    every shape with FPGPU_MATMUL_MFMA = 1 (the plan's cost model would leave these small ones to the VALU kernel): ragged
+    tiles, one k-step, several persistent tiles per workgroup (more than 256 tiles), k long enough for two and three k
+    parts of 255 / n64 k-steps each (the scratch is then added to, not stored), uniform elements and the values with the
+    largest signed digits; == oracle == VALU kernel, bit for bit."""
+    from oracle.fp_oracle import Oracle
+    from soak_inversion_plans import rand_elems
+    _, p, n64 = case
+    f, o = cpa.MontyField(p, n64), Oracle(p, n64)
+    rng = np.random.default_rng(n64 + 77)
+    rnd = random.Random(n64)
+    full = int.from_bytes(b"\x7f" * (8 * n64), "little")
+    edge = [0, 1, p - 1, p - 2, full % p, (full + 1) % p, (p + full) % p, int.from_bytes(b"\x80" * (8 * n64), "little") % p,
+            (p - int.from_bytes(b"\x80" * (8 * n64), "little")) % p, p >> 1, (p >> 1) + 1,
+            int.from_bytes(b"\xff" * (8 * n64 - 1) + b"\x00", "little") % p]
+    part = 64 * (255 // n64)
+    tuning("FPGPU_MATMUL_MFMA", 1)
+    shapes = [(1, 1, 2), (64, 64, 64), (65, 63, 130), (17, 300, 33), (200, part + 70, 210), (180, 2 * part + 1, 190), (1100, 3, 1100)]   # (more than 128 tiles of 16 x 16: below that a long k goes to the k-split VALU path)
+    for m, k, n in shapes:
+        for mode in ("uniform", "edge"):
+            if mode == "edge" and m * k * n > 3_000_000:
+                continue
+            if mode == "uniform":
+                A, B = rand_elems(rng, m * k, n64, p), rand_elems(rng, k * n, n64, p)
+            else:
+                A = ints_to_array([rnd.choice(edge) for _ in range(m * k)], n64)
+                B = ints_to_array([rnd.choice(edge) for _ in range(k * n)], n64)
+            nb = f.matmul_workspace_bytes(m, k, n)
+            assert nb >= 8 * n64 * (m * k + k * n), (m, k, n, nb)       # digit planes of both operands + scratch
+            got = _dev_matmul(cpa, f, A, B, m, k, n, True).reshape(m * n, n64)
+            if m * k * n > 20_000_000:
+                # the long products: the oracle on the first and last rows, every output against the VALU kernel (no
+                # workspace), which the other tests hold to the oracle
+                for r0 in (0, m - 2):
+                    want = o.matmul(A[r0 * k:(r0 + 2) * k], B, 2, k, n, threads=0)
+                    assert np.array_equal(got[r0 * n:(r0 + 2) * n], want.reshape(2 * n, n64)), (m, k, n, mode, "matrix cores", r0)
+                assert np.array_equal(got, _dev_matmul(cpa, f, A, B, m, k, n, False).reshape(m * n, n64)), (m, k, n, mode, "vs VALU")
+            else:
+                want = o.matmul(A, B, m, k, n, threads=0)
+                assert np.array_equal(got, want.reshape(m * n, n64)), (m, k, n, mode, "matrix cores")
+    m, k, n = 70, 130, 66
+    A, B = rand_elems(rng, m * k, n64, p), rand_elems(rng, k * n, n64, p)
+    want = o.matmul(A, B, m, k, n, threads=0)
+    assert np.array_equal(f.matmul(A, B, m, k, n), want), "host call"
+    tuning("FPGPU_MATMUL_MFMA", 0)
+    assert f.matmul_workspace_bytes(m, k, n) == 0
+    assert np.array_equal(_dev_matmul(cpa, f, A, B, m, k, n, False).reshape(want.shape), want), "VALU kernel"
+
+
+def test_matmul_multi_limb_matrix_core_extreme_digits_and_fallback(cpa, tuning):
+    """Every digit product at its extreme over a full k part (the int32 bound: 255 k-steps shared by the n64 pairs of a
+    limb diagonal), and a non-canonical input whose x - p has no digit form: flagged on the device, k_matmul answers."""
+    from oracle.fp_oracle import Oracle
+    tuning("FPGPU_MATMUL_MFMA", 1)
+    for p, n64 in ((2**256 - 2**32 - 977, 4), (2**127 - 1, 2), (2**512 - 569, 8)):
+        f, o = cpa.MontyField(p, n64), Oracle(p, n64)
+        full = int.from_bytes(b"\x7f" * (8 * n64), "little")
+        m, k, n = 2, 64 * (255 // n64), 3
+        for va, vb in ((full % p, full % p), ((full + 1) % p, (full + 1) % p), (full % p, (full + 1) % p)):
+            A, B = ints_to_array([va] * (m * k), n64), ints_to_array([vb] * (k * n), n64)
+            want = o.matmul(A, B, m, k, n, threads=0)
+            assert np.array_equal(_dev_matmul(cpa, f, A, B, m, k, n, True).reshape(want.shape), want), (n64, hex(va), hex(vb))
+    p, n64 = 2**127 - 1, 2
+    f, o = cpa.MontyField(p, n64), Oracle(p, n64)
+    m, k, n = 5, 70, 9
+    rnd = random.Random(5)
+    A = ints_to_array([rnd.randrange(p) for _ in range(m * k)], n64)
+    B = ints_to_array([rnd.randrange(p) for _ in range(k * n)], n64)
+    A[7, :] = np.uint64(2**64 - 1)                       # 2^128 - 1 >= p, and 2^128 - 1 - p = 2^127 has no 16-digit form
+    want = _dev_matmul(cpa, f, A, B, m, k, n, False)     # the VALU kernel takes any a < R, as monty_mul does
+    assert np.array_equal(_dev_matmul(cpa, f, A, B, m, k, n, True), want)
+    A2 = A.copy()
+    A2[7] = ints_to_array([(2**128 - 1) % p], n64)[0]
+    assert np.array_equal(_dev_matmul(cpa, f, A2, B, m, k, n, True).reshape(-1, n64), o.matmul(A2, B, m, k, n, threads=0).reshape(-1, n64))
+
+
 @pytest.mark.parametrize("name", ["bn254_fr", "goldilocks", "bls12_381_fq", "odd_composite_128"])
 def test_pow_vs_oracle(cpa, name):
     # SURVEY.md 8f N1: batched pow, one exponent per batch; oracle = the reference's 4-bit-window AMM ladder
