@@ -261,6 +261,8 @@ def main():
             extra["matmul_goldilocks"] = bench_matmul(args, world, rank, distributed, time_steps, False, samples)
         if args.workload != "matvec":
             extra["matvec_bn254"] = bench_matvec(args, f, world, rank, distributed, time_steps, False, samples)
+        if world == 1:
+            extra["matmul_bn254"] = bench_matmul_multilimb(f, time_steps)
         extra["spmv_bn254"] = bench_spmv(f, rank, time_steps)
         extra["pow_bn254"] = bench_pow(f, a, out, time_steps)
         if rank == 0:
@@ -448,6 +450,31 @@ def bench_matmul(args, world, rank, distributed, time_steps, primary, samples):
                             "kernel": "k_matmul_mfma_1limb"},
                "verified_vs_oracle": None}
     return res
+
+
+def bench_matmul_multilimb(f, time_steps, dim=2048):
+    """Multi-limb mat-mul (BN254 Fr, dim^3; not a BASELINE configuration) on the int8 matrix cores as n64 x n64
+    single-limb passes (fp_matmul_mfma_limbs.cuh), with the VALU kernel on the same product timed in the same run and
+    the two results compared bit for bit (the VALU kernel is the one the parity tests hold to the oracle at this size)."""
+    import torch
+    from crypto_primitives_amd import _lib
+    A, B = f.random_dev(dim * dim, 0x71), f.random_dev(dim * dim, 0x72)
+    C, C2 = f.alloc(dim * dim), f.alloc(dim * dim)
+    nb = f.matmul_workspace_bytes(dim, dim, dim)
+    ws = torch.empty(max(nb, 256), dtype=torch.uint8, device="cuda")
+    wall, kern = time_steps(lambda: f.matmul_dev(A, B, C, dim, dim, dim, workspace=ws), 3, 2)
+    _lib.tuning_set("FPGPU_MATMUL_MFMA", 0)
+    try:
+        _, kern_valu = time_steps(lambda: f.matmul_dev(A, B, C2, dim, dim, dim), 1, 1)
+    finally:
+        _lib.tuning_set("FPGPU_MATMUL_MFMA")
+    torch.cuda.synchronize()
+    n64 = f.n64
+    tops = 2.0 * 64.0 * n64 * n64 * dim ** 3 / kern / 1e12
+    return {"Gterms_per_s": dim ** 3 / kern / 1e9, "ms_per_matmul": kern * 1e3, "dim": dim, "workspace_MiB": nb / 2 ** 20,
+            "int8_mfma_Tops_per_gpu": tops, "int8_mfma_peak_Tops": MFMA_I8_PEAK_TOPS, "mfma_frac": tops / MFMA_I8_PEAK_TOPS,
+            "kernels": "k_mfl_digitize x2 + k_matmul_mfma_limbs (%d x %d passes of the v_mfma_i32_16x16x64_i8 loop)" % (n64, n64),
+            "valu_kernel_ms_same_run": kern_valu * 1e3, "same_bits_as_valu_kernel": bool(torch.equal(C, C2))}
 
 
 def bench_matvec(args, f, world, rank, distributed, time_steps, primary, samples):

@@ -186,7 +186,7 @@ inline MflPlan make_mfl_plan(uint32_t n64, size_t m, size_t k, size_t n, bool fo
     MflPlan pl{};
     if (n64 < 2 || n64 > 8 || m == 0 || n == 0 || k == 0) return pl;
     const size_t rb = (m + 63) / 64, cb = (n + 63) / 64, ks = (k + 63) / 64;
-    if (rb * cb >= (1u << 28) || ks >= (1u << 24)) return pl;
+    if (rb * cb >= (1u << 28) || ks >= (1u << 24) || rb * ks >= (1u << 31) || cb * ks >= (1u << 31)) return pl;   // (grids of the digitisers)
     if (!forced) {
         const double nl2 = (double)n64 * n64;
         const double valu_us = (double)m * n * k * nl2 * 0.21e-6;
