@@ -321,9 +321,9 @@ hipError_t Launch<N>::matmul(const fpgpu_ctx* ctx, const void* A, const void* B,
             uint32_t* flag = (uint32_t*)ws;
             if (hipError_t e = hipMemsetAsync(flag, 0, 4, s); e != hipSuccess) return e;
             const unsigned wa = pl.rblocks * pl.ksteps, wb = pl.cblocks * pl.ksteps;  // x4 waves = one workgroup each
-            hipLaunchKernelGGL((k_mfl_digitize<N, false>), dim3(wa), dim3(256), 0, s, (const uint32_t*)A, m, k, k,
+            hipLaunchKernelGGL((k_mfl_digitize<N, false>), dim3(wa, N / 2), dim3(256), 0, s, (const uint32_t*)A, m, k, k,
                                ws + pl.a_off, pl.plane_a, pl.rblocks, pl.ksteps, flag, make_params<N>(ctx));
-            hipLaunchKernelGGL((k_mfl_digitize<N, true>), dim3(wb), dim3(256), 0, s, (const uint32_t*)B, n, k, n,
+            hipLaunchKernelGGL((k_mfl_digitize<N, true>), dim3(wb, N / 2), dim3(256), 0, s, (const uint32_t*)B, n, k, n,
                                ws + pl.b_off, pl.plane_b, pl.cblocks, pl.ksteps, flag, make_params<N>(ctx));
             hipLaunchKernelGGL((k_matmul_mfma_limbs<N>), dim3(pl.grid), dim3(256), 0, s, ws + pl.a_off, ws + pl.b_off,
                                pl.plane_a, pl.plane_b, (uint32_t*)C, m, n, pl.rblocks, pl.cblocks, pl.ksteps,

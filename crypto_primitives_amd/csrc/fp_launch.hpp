@@ -192,8 +192,8 @@ inline MflPlan make_mfl_plan(uint32_t n64, size_t m, size_t k, size_t n, bool fo
         const double valu_us = (double)m * n * k * nl2 * 0.21e-6;
         const double rounds = (double)((rb * cb + 255) / 256);
         // measured (tools/exp_matmul_limbs.py, 256 ... 4096 on a side, 128 to 512 bits): 3.0 us per pair and k-step of a tile
-        // with the epilogues and pipeline restarts of a limb diagonal in it, 3.25 ps x n64^2 per digitised element, 40 us of launches
-        const double mfma_us = rounds * ks * nl2 * 3.0 + (double)(m + n) * k * nl2 * 3.25e-6 + 40.0;
+        // with the epilogues and pipeline restarts of a limb diagonal in it, 1.65 ps x n64^2 per digitised element, 40 us of launches
+        const double mfma_us = rounds * ks * nl2 * 3.0 + (double)(m + n) * k * nl2 * 1.65e-6 + 40.0;
         if (mfma_us >= valu_us) return pl;
     }
     pl.usable = true;
