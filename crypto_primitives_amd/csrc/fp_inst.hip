@@ -325,9 +325,15 @@ hipError_t Launch<N>::matmul(const fpgpu_ctx* ctx, const void* A, const void* B,
                                ws + pl.a_off, pl.plane_a, pl.rblocks, pl.ksteps, flag, make_params<N>(ctx));
             hipLaunchKernelGGL((k_mfl_digitize<N, true>), dim3(wb, N / 2), dim3(256), 0, s, (const uint32_t*)B, n, k, n,
                                ws + pl.b_off, pl.plane_b, pl.cblocks, pl.ksteps, flag, make_params<N>(ctx));
+            uint32_t* dst = pl.zparts > 1 ? (uint32_t*)(ws + pl.p_off) : (uint32_t*)C;
             hipLaunchKernelGGL((k_matmul_mfma_limbs<N>), dim3(pl.grid), dim3(256), 0, s, ws + pl.a_off, ws + pl.b_off,
-                               pl.plane_a, pl.plane_b, (uint32_t*)C, m, n, pl.rblocks, pl.cblocks, pl.ksteps,
+                               pl.plane_a, pl.plane_b, dst, m, n, pl.rblocks, pl.cblocks, pl.ksteps, pl.zparts, pl.zsteps,
                                (uint32_t*)(ws + pl.t_off), (const uint32_t*)flag, make_params<N>(ctx));
+            if (pl.zparts > 1) {   // (sums whatever the scratch holds when the flag is up: k_matmul below then overwrites C)
+                const size_t outs = m * n, cw = (outs + kBlock / 64 - 1) / (kBlock / 64);
+                hipLaunchKernelGGL((k_matvec_combine<N>), dim3((unsigned)cw), dim3(kBlock), 0, s, (const uint32_t*)dst,
+                                   (uint32_t*)C, outs, pl.zparts, make_params<N>(ctx));
+            }
             gate = flag;   // the VALU kernel below then runs only if some input had no digit form
         }
     }

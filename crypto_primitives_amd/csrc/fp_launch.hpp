@@ -179,35 +179,49 @@ inline MfmaPlan make_mfma_plan(uint32_t n64, size_t m, size_t k, size_t n) {
 // k-step of a 64 x 64 tile on ONE CU, so the tiles must come near the CUs' number and k must amortise the launches.
 struct MflPlan {
     bool usable;
-    uint32_t rblocks, cblocks, ksteps, grid;
-    size_t plane_a, plane_b, a_off, b_off, t_off, bytes;
+    uint32_t rblocks, cblocks, ksteps, grid, zparts, zsteps;
+    size_t plane_a, plane_b, a_off, b_off, t_off, p_off, bytes;
 };
 inline MflPlan make_mfl_plan(uint32_t n64, size_t m, size_t k, size_t n, bool forced = false) {
     MflPlan pl{};
     if (n64 < 2 || n64 > 8 || m == 0 || n == 0 || k == 0) return pl;
     const size_t rb = (m + 63) / 64, cb = (n + 63) / 64, ks = (k + 63) / 64;
     if (rb * cb >= (1u << 28) || ks >= (1u << 24) || rb * ks >= (1u << 31) || cb * ks >= (1u << 31)) return pl;   // (grids of the digitisers)
+    // too few tiles for the chip's 256 CUs: k is split over z parts per tile, each a work item of its own, and the parts'
+    // canonical residues are added per output (k_matvec_combine) -- 512 x 4096 x 512 BN254: 64 tiles, 2.7 ms on 64 CUs
+    const size_t tiles = rb * cb;
+    size_t z = tiles >= 192 ? 1 : 256 / tiles;
+    if (z > ks) z = ks;
+    const size_t zs = (ks + z - 1) / z;
+    z = (ks + zs - 1) / zs;
     if (!forced) {
         const double nl2 = (double)n64 * n64;
-        const double valu_us = (double)m * n * k * nl2 * 0.21e-6;
-        const double rounds = (double)((rb * cb + 255) / 256);
+        // the VALU kernel: the chip's rate, but never less than ONE workgroup's walk over k (a 16 x 16 tile, a lane per
+        // output: 0.25 us x n64^2 / 16 per term -- 128 x 2048 x 128 BN254 takes 0.63 ms, not the 0.11 the rate alone gives)
+        const double valu_rate_us = (double)m * n * k * nl2 * 0.21e-6, valu_walk_us = (double)k * nl2 * 0.0156;
+        const double valu_us = valu_rate_us > valu_walk_us ? valu_rate_us : valu_walk_us;
+        const double rounds = (double)((tiles * z + 255) / 256);
         // measured (tools/exp_matmul_limbs.py, 256 ... 4096 on a side, 128 to 512 bits): 3.0 us per pair and k-step of a tile
-        // with the epilogues and pipeline restarts of a limb diagonal in it, 1.65 ps x n64^2 per digitised element, 40 us of launches
-        const double mfma_us = rounds * ks * nl2 * 3.0 + (double)(m + n) * k * nl2 * 1.65e-6 + 40.0;
+        // with the epilogues and pipeline restarts of a limb diagonal in it, ~5 us x n64^2 per work item for its diagonals'
+        // epilogues and its 16 reductions per lane, 1.65 ps x n64^2 per digitised element, 40 us of launches
+        const double mfma_us = rounds * (zs * nl2 * 3.0 + nl2 * 5.0) + (double)(m + n) * k * nl2 * 1.65e-6 + 40.0 + (z > 1 ? 10.0 : 0.0);
         if (mfma_us >= valu_us) return pl;
     }
     pl.usable = true;
     pl.rblocks = (uint32_t)rb;
     pl.cblocks = (uint32_t)cb;
     pl.ksteps = (uint32_t)ks;
-    const size_t tiles8 = (rb * cb + 7) / 8 * 8;
-    pl.grid = (uint32_t)(tiles8 < 256 ? tiles8 : 256);
+    pl.zparts = (uint32_t)z;
+    pl.zsteps = (uint32_t)zs;
+    const size_t items8 = (tiles + 7) / 8 * 8 * z;
+    pl.grid = (uint32_t)(items8 < 256 ? items8 : 256);
     pl.plane_a = rb * ks * 32768;
     pl.plane_b = cb * ks * 32768;
     pl.a_off = 256;
     pl.b_off = pl.a_off + n64 * pl.plane_a;
     pl.t_off = pl.b_off + n64 * pl.plane_b;
-    pl.bytes = pl.t_off + (size_t)pl.grid * (2 * n64 - 1) * 6 * 4096 * 4;
+    pl.p_off = pl.t_off + (size_t)pl.grid * (2 * n64 - 1) * 6 * 4096 * 4;
+    pl.bytes = pl.p_off + (z > 1 ? ((m * n * z * 8 * n64 + 255) / 256) * 256 : 0);
     return pl;
 }
 constexpr int kFoldBlocks = 2048;  // partials of the first fold pass (workspace = kFoldBlocks elements)

@@ -18,6 +18,8 @@
 // the canonical residue: bit-identical to the reference's fold of mul and add.
 // Signed digits of an element: x itself when x <= 0x7f7f..7f, else x - p; an input that fits neither (non-canonical)
 // raises the flag, this kernel returns at once and k_matmul<N>, gated on the flag, runs instead.
+// A product of few tiles would occupy as many CUs: the plan then splits k over z work items per tile (fp_launch.hpp),
+// each with its own reduction, and k_matvec_combine adds the z canonical residues of every output.
 #pragma once
 #include "fp_matmul_mfma.cuh"
 
@@ -115,8 +117,11 @@ template <int N>
 __global__ __launch_bounds__(256) void k_matmul_mfma_limbs(const uint8_t* __restrict__ Aw, const uint8_t* __restrict__ Bw,
                                                            size_t plane_a, size_t plane_b, uint32_t* __restrict__ Cm, size_t m,
                                                            size_t n, uint32_t rblocks, uint32_t cblocks, uint32_t ksteps,
-                                                           uint32_t* __restrict__ scratch, const uint32_t* __restrict__ flag,
-                                                           const FpParams<N> P) {
+                                                           uint32_t zparts, uint32_t zsteps, uint32_t* __restrict__ scratch,
+                                                           const uint32_t* __restrict__ flag, const FpParams<N> P) {
+    // zparts > 1 (too few tiles to fill the chip): work item (z, tile) takes the k-steps [z * zsteps, (z + 1) * zsteps) of its
+    // tile and writes the canonical residue of that partial sum to Cm[(row * n + col) * zparts + z] -- Cm is then the
+    // launcher's scratch and k_matvec_combine adds the parts of every output (as for k_matmul's k parts)
     static_assert(N >= 4 && N % 2 == 0, "multi-limb kernel");
     constexpr int NL = N / 2, NW = 2 * NL - 1, SL = 2 * N + 2;
     constexpr uint32_t kPart = mfl_part_ksteps(NL);
@@ -130,11 +135,14 @@ __global__ __launch_bounds__(256) void k_matmul_mfma_limbs(const uint8_t* __rest
     uint32_t* const mine = scratch + (size_t)blockIdx.x * mfl_scratch_words(NL) + (size_t)wave * 16 * 64 + lane;
     const uint32_t total8 = 8 * ((rblocks * cblocks + 7) / 8);
 
-    for (uint32_t tb = blockIdx.x; tb < total8; tb += gridDim.x) {   // gridDim.x is a multiple of 8: a workgroup stays on its XCD's run of tiles
+    // items z * total8 + tile: gridDim.x and total8 are multiples of 8, so a workgroup stays on its XCD's run of tiles
+    for (uint32_t item = blockIdx.x; item < total8 * zparts; item += gridDim.x) {
+        const uint32_t tb = item % total8, z = item / total8;
         uint32_t rb, cb;
         if (!mf_tile_of(tb, rblocks, cblocks, rb, cb)) continue;     // (uniform over the workgroup)
-        for (uint32_t kp0 = 0; kp0 < ksteps; kp0 += kPart) {
-            const uint32_t kpn = ksteps - kp0 < kPart ? ksteps - kp0 : kPart;
+        const uint32_t ks_lo = z * zsteps, ks_hi = ks_lo + zsteps < ksteps ? ks_lo + zsteps : ksteps;
+        for (uint32_t kp0 = ks_lo; kp0 < ks_hi; kp0 += kPart) {
+            const uint32_t kpn = ks_hi - kp0 < kPart ? ks_hi - kp0 : kPart;
 #pragma unroll 1
             for (int w = 0; w < NW; w++) {
                 const int u0 = w - (NL - 1) > 0 ? w - (NL - 1) : 0, u1 = w < NL - 1 ? w : NL - 1;
@@ -202,7 +210,7 @@ __global__ __launch_bounds__(256) void k_matmul_mfma_limbs(const uint8_t* __rest
                                 for (int t = q + 2; t < 6; t++) S[t] = __builtin_addc(S[t], sg, cy, &cy);
                             }
                             uint32_t* slot = mine + (size_t)w * 6 * 4096 + (size_t)((rt * 2 + ct) * 4 + e) * 64;
-                            if (kp0 != 0) {
+                            if (kp0 != ks_lo) {
                                 unsigned cy = 0;
 #pragma unroll
                                 for (int t = 0; t < 6; t++) S[t] = __builtin_addc(S[t], slot[(size_t)t * 4096], cy, &cy);
@@ -254,7 +262,7 @@ __global__ __launch_bounds__(256) void k_matmul_mfma_limbs(const uint8_t* __rest
 #pragma unroll
             for (int l = 0; l < N; l++) corr[l] = sg ? r2[l] : 0u;   // 2^(32*3N) R^-1 = R^2 (mod p) comes back out
             mod_sub<N>(res, v2, corr, P);
-            store_elem<N>(Cm, row * n + col, res);
+            store_elem<N>(Cm, zparts > 1 ? (row * n + col) * zparts + z : row * n + col, res);
         }
     }
 }

@@ -217,10 +217,10 @@ int fpgpu_spmv_dev(const fpgpu_ctx *ctx, const void *vals, const uint32_t *col_i
  * `workspace` is optional device scratch (256-byte aligned) of at least
  * fpgpu_matmul_workspace_bytes(ctx, m, k, n) bytes; with it, single-limb fields (n64 == 1,
  * k <= 16320) run on the matrix cores (int8 digit planes of A and B^T live there), and so do
- * multi-limb fields (n64 = 2 ... 8, any k) from about 64 output tiles of 64 x 64 on, as n64 x n64
+ * multi-limb fields (n64 = 2 ... 8, any k) from about 256 x 1024 x 256 on, as n64 x n64
  * single-limb products (digit planes of every limb plus up to 256 x (2 n64 - 1) x 96 KiB of scratch:
- * 232 MiB for 1024^3 at 256 bits, 3.4 against 0.92 ms; below that size the function reports what the
- * VALU paths need).  Without it (NULL), or where that size is 0, the VALU kernels run.  Results are identical.  Two shapes
+ * 232 MiB for 1024^3 at 256 bits, 3.4 against 0.87 ms; products of few output tiles split k over
+ * workgroups through it as well; below that size the function reports what the VALU paths need).  Without it (NULL), or where that size is 0, the VALU kernels run.  Results are identical.  Two shapes
  * use the workspace at every width: a small output over a long k (at most 128 tiles of 16 x 16,
  * k >= 4096) splits k over workgroups through it -- without it such a product runs on a few
  * workgroups (16 x 2^20 x 16: 335 ms against 1.0) -- and a product with one column (n == 1) is

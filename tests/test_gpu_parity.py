@@ -515,9 +515,9 @@ _MFL_MODULI = [("bn254", 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F
 def test_matmul_multi_limb_matrix_core_path_vs_oracle(cpa, tuning, case):
     """Multi-limb mat-mul as n64 x n64 single-limb products on the int8 matrix cores (fp_matmul_mfma_limbs.cuh), forced for
     every shape with FPGPU_MATMUL_MFMA = 1 (the plan's cost model would leave these small ones to the VALU kernel): ragged
-    tiles, one k-step, several persistent tiles per workgroup (more than 256 tiles), k long enough for two and three k
-    parts of 255 / n64 k-steps each (the scratch is then added to, not stored), uniform elements and the values with the
-    largest signed digits; == oracle == VALU kernel, bit for bit."""
+    tiles, one k-step, several persistent tiles per workgroup (more than 256 tiles), k split over work items where the
+    tiles are few, k long enough for two k parts of 255 / n64 k-steps each per item (the scratch is then added to, not
+    stored), uniform elements and the values with the largest signed digits; == oracle == VALU kernel, bit for bit."""
     from oracle.fp_oracle import Oracle
     from soak_inversion_plans import rand_elems
     _, p, n64 = case
@@ -530,7 +530,10 @@ def test_matmul_multi_limb_matrix_core_path_vs_oracle(cpa, tuning, case):
             int.from_bytes(b"\xff" * (8 * n64 - 1) + b"\x00", "little") % p]
     part = 64 * (255 // n64)
     tuning("FPGPU_MATMUL_MFMA", 1)
-    shapes = [(1, 1, 2), (64, 64, 64), (65, 63, 130), (17, 300, 33), (200, part + 70, 210), (180, 2 * part + 1, 190), (1100, 3, 1100)]   # (more than 128 tiles of 16 x 16: below that a long k goes to the k-split VALU path)
+    # few tiles: k split over work items (z parts per tile, added per output); 225 tiles over two k parts of 255 / n64
+    # k-steps (the scratch is added to); 121 tiles in two z parts of more than one k part each; 324 tiles of one k-step
+    shapes = [(1, 1, 2), (64, 64, 64), (65, 63, 130), (17, 300, 33), (200, part + 70, 210), (900, part + 70, 900),
+              (700, 2 * part + 200, 700), (1100, 3, 1100)]
     for m, k, n in shapes:
         for mode in ("uniform", "edge"):
             if mode == "edge" and m * k * n > 3_000_000:

@@ -67,7 +67,8 @@ def main():
     if mode in ("all", "time"):
         for name, p, n64 in FIELDS[:2] + FIELDS[5:6]:
             f = cpa.MontyField(p, n64)
-            for m, k, n in ((1024, 1024, 1024), (2048, 2048, 2048), (4096, 1024, 4096), (512, 4096, 512), (256, 1024, 256), (3000, 500, 3000), (1024, 8192, 1024)):
+            for m, k, n in ((1024, 1024, 1024), (2048, 2048, 2048), (4096, 1024, 4096), (512, 4096, 512), (256, 1024, 256), (3000, 500, 3000), (1024, 8192, 1024),
+                            (128, 2048, 128), (300, 300, 300), (640, 640, 640), (100, 10000, 100), (64, 512, 64), (1000, 1000, 1000)):
                 A, B = f.random_dev(m * k, 1), f.random_dev(k * n, 2)
                 C0, C1 = f.alloc(m * n), f.alloc(m * n)
                 _lib.tuning_set("FPGPU_MATMUL_MFMA", 0)
