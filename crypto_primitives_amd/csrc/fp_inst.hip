@@ -1,11 +1,7 @@
 // fp_inst.hip -- instantiates every kernel launcher for ONE limb count (-DFPGPU_N=N).
 #include "fp_kernels.cuh"
 #include "fp_launch.hpp"
-#if FPGPU_N == 2
-#include "fp_matmul_mfma.cuh"
-#elif FPGPU_N >= 4
-#include "fp_matmul_mfma_limbs.cuh"
-#endif
+#include "fp_matmul_mfma_limbs.cuh"   // (includes fp_matmul_mfma.cuh, whose kernel only N = 2 instantiates)
 #include "fp_matvec_mfma.cuh"
 
 #ifndef FPGPU_N
@@ -284,9 +280,31 @@ hipError_t Launch<N>::matmul(const fpgpu_ctx* ctx, const void* A, const void* B,
             const MfmaPlan pl = make_mfma_plan(ctx->n64, m, k, n);
             const bool mfma = pl.usable && workspace && workspace_bytes >= pl.bytes && tune.matmul_mfma != 0;
             if (!mfma) {
+                // k beyond the int32 accumulators of k_matmul_mfma_1limb: the limb kernel with one limb (k in parts of 255
+                // k-steps, k split over work items where the tiles are few), the VALU kernel behind its flag
+                const uint32_t* gate1 = nullptr;
+                const MflPlan ml = pl.usable ? MflPlan{} : make_mfl_plan(ctx->n64, m, k, n, tune.matmul_mfma > 0);
+                if (ml.usable && workspace && workspace_bytes >= ml.bytes && tune.matmul_mfma != 0) {
+                    uint8_t* ws = (uint8_t*)workspace;
+                    uint32_t* flag = (uint32_t*)ws;
+                    if (hipError_t e = hipMemsetAsync(flag, 0, 4, s); e != hipSuccess) return e;
+                    hipLaunchKernelGGL((k_mfl_digitize<N, false>), dim3(ml.rblocks * ml.ksteps, 1), dim3(256), 0, s, (const uint32_t*)A, m,
+                                       k, k, ws + ml.a_off, ml.plane_a, ml.rblocks, ml.ksteps, flag, make_params<N>(ctx));
+                    hipLaunchKernelGGL((k_mfl_digitize<N, true>), dim3(ml.cblocks * ml.ksteps, 1), dim3(256), 0, s, (const uint32_t*)B, n,
+                                       k, n, ws + ml.b_off, ml.plane_b, ml.cblocks, ml.ksteps, flag, make_params<N>(ctx));
+                    uint32_t* dst = ml.zparts > 1 ? (uint32_t*)(ws + ml.p_off) : (uint32_t*)C;
+                    hipLaunchKernelGGL((k_matmul_mfma_limbs<N>), dim3(ml.grid), dim3(256), 0, s, ws + ml.a_off, ws + ml.b_off,
+                                       ml.plane_a, ml.plane_b, dst, m, n, ml.rblocks, ml.cblocks, ml.ksteps, ml.zparts, ml.zsteps,
+                                       (uint32_t*)(ws + ml.t_off), (const uint32_t*)flag, make_params<N>(ctx));
+                    if (ml.zparts > 1) {
+                        const size_t outs = m * n, cw = (outs + kBlock / 64 - 1) / (kBlock / 64);
+                        hipLaunchKernelGGL((k_matvec_combine<N>), dim3((unsigned)cw), dim3(kBlock), 0, s, (const uint32_t*)dst,
+                                           (uint32_t*)C, outs, ml.zparts, make_params<N>(ctx));
+                    }
+                    gate1 = flag;
+                }
                 hipLaunchKernelGGL((k_matmul_1limb<N>), dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, s,
-                                   (const uint2*)A, (const uint2*)B, (uint2*)C, m, k, n, (const uint32_t*)nullptr,
-                                   make_params<N>(ctx));
+                                   (const uint2*)A, (const uint2*)B, (uint2*)C, m, k, n, gate1, make_params<N>(ctx));
                 return hipSuccess;
             }
             uint8_t* ws = (uint8_t*)workspace;

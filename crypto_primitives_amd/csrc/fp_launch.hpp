@@ -184,7 +184,7 @@ struct MflPlan {
 };
 inline MflPlan make_mfl_plan(uint32_t n64, size_t m, size_t k, size_t n, bool forced = false) {
     MflPlan pl{};
-    if (n64 < 2 || n64 > 8 || m == 0 || n == 0 || k == 0) return pl;
+    if (n64 < 1 || n64 > 8 || m == 0 || n == 0 || k == 0) return pl;   // (n64 == 1: only asked for k beyond make_mfma_plan's 16320)
     const size_t rb = (m + 63) / 64, cb = (n + 63) / 64, ks = (k + 63) / 64;
     if (rb * cb >= (1u << 28) || ks >= (1u << 24) || rb * ks >= (1u << 31) || cb * ks >= (1u << 31)) return pl;   // (grids of the digitisers)
     // too few tiles for the chip's 256 CUs: k is split over z parts per tile, each a work item of its own, and the parts'

@@ -115,6 +115,13 @@ __device__ __forceinline__ bool mf_tile_of(uint32_t b, uint32_t rblocks, uint32_
 #define MF_MFMA(ACC, A, B) asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0" : "+a"(ACC) : "v"(A), "v"(B))
 #define MF_LDS_READ(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:" #OFF : "=v"(DST) : "v"(ADDR) : "memory")
 #define MF_WAIT_LGKM(CNT) asm volatile("s_waitcnt lgkmcnt(" #CNT ")" ::: "memory")
+// Nothing ties a bare `s_nop` asm to the accumulators: the compiler is free to hoist its own v_accvgpr_read / _mov of an
+// MFMA result ABOVE the wait (it did in k_matmul_mfma_limbs<2>: one output in sixteen wrong).  An empty asm that "modifies"
+// every accumulator, placed after the s_nop (volatile asms keep their order), makes every later read depend on it.
+#define MF_FENCE_ACC(ACC)                                                               \
+    _Pragma("unroll") for (int d_ = 0; d_ < 15; d_++)                                   \
+        _Pragma("unroll") for (int r_ = 0; r_ < 2; r_++)                                \
+            _Pragma("unroll") for (int c_ = 0; c_ < 2; c_++) asm volatile("" : "+a"(ACC[d_][r_][c_]))
 
 // The three places where a timing-only build may alter the main loop (tools/variants/matmul_timing.hpp,
 // force-included by tools/build_variant.sh; such builds give wrong results and are never shipped).
@@ -183,6 +190,7 @@ __global__ __launch_bounds__(256) void k_matmul_mfma_1limb(const uint8_t* __rest
     }
     // the compiler does not see the asm MFMAs' writes: cover the MFMA-write -> accvgpr-read hazard by hand
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    MF_FENCE_ACC(acc);
 
     // ---- recombine the diagonals and reduce: C/D layout col = lane & 15, row = 4 (lane >> 4) + reg
     uint32_t onep[2] = {1u, 0u}, oneR[2], r2[2], zero[2] = {0u, 0u};

@@ -18,6 +18,8 @@
 // the canonical residue: bit-identical to the reference's fold of mul and add.
 // Signed digits of an element: x itself when x <= 0x7f7f..7f, else x - p; an input that fits neither (non-canonical)
 // raises the flag, this kernel returns at once and k_matmul<N>, gated on the flag, runs instead.
+// Single-limb fields (N = 2) come here when k exceeds what k_matmul_mfma_1limb's int32 accumulators hold (16320): one pair,
+// k in parts of 255 k-steps through the same scratch.
 // A product of few tiles would occupy as many CUs: the plan then splits k over z work items per tile (fp_launch.hpp),
 // each with its own reduction, and k_matvec_combine adds the z canonical residues of every output.
 #pragma once
@@ -122,7 +124,7 @@ __global__ __launch_bounds__(256) void k_matmul_mfma_limbs(const uint8_t* __rest
     // zparts > 1 (too few tiles to fill the chip): work item (z, tile) takes the k-steps [z * zsteps, (z + 1) * zsteps) of its
     // tile and writes the canonical residue of that partial sum to Cm[(row * n + col) * zparts + z] -- Cm is then the
     // launcher's scratch and k_matvec_combine adds the parts of every output (as for k_matmul's k parts)
-    static_assert(N >= 4 && N % 2 == 0, "multi-limb kernel");
+    static_assert(N >= 2 && N % 2 == 0, "whole 64-bit limbs (N = 2: single-limb fields with k beyond k_matmul_mfma_1limb's 16320)");
     constexpr int NL = N / 2, NW = 2 * NL - 1, SL = 2 * N + 2;
     constexpr uint32_t kPart = mfl_part_ksteps(NL);
     __shared__ __attribute__((aligned(1024))) uint8_t lds[2 * 2 * kMF_CHUNK];
@@ -188,6 +190,7 @@ __global__ __launch_bounds__(256) void k_matmul_mfma_limbs(const uint8_t* __rest
                     __syncthreads();
                 }
                 asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // MFMA write -> accvgpr read, invisible to the compiler
+                MF_FENCE_ACC(acc);
                 // T_w (+)= sum_d D_d 256^d in 192-bit two's complement
 #pragma unroll
                 for (int rt = 0; rt < 2; rt++)

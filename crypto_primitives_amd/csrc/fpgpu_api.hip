@@ -466,7 +466,10 @@ size_t fpgpu_matmul_workspace_bytes(const fpgpu_ctx* ctx, size_t m, size_t k, si
         return ml.usable && tuning().matmul_mfma != 0 ? ml.bytes : 0;
     }
     const MfmaPlan pl = make_mfma_plan(ctx->n64, m, k, n);
-    return pl.usable ? pl.bytes : 0;
+    if (pl.usable) return pl.bytes;
+    // a single-limb product with k beyond the int32 accumulators: the limb kernel's planes and scratch
+    const MflPlan ml = make_mfl_plan(ctx->n64, m, k, n, tuning().matmul_mfma > 0);
+    return ml.usable && tuning().matmul_mfma != 0 ? ml.bytes : 0;
 }
 
 int fpgpu_matmul_dev(const fpgpu_ctx* ctx, const void* A, const void* B, void* C, size_t m, size_t k, size_t n,

@@ -504,6 +504,43 @@ def test_matmul_matrix_core_falls_back_on_undigitisable_inputs(cpa):
     assert np.array_equal(got2.reshape(-1), o.matmul(A2, B, m, k, n, threads=0).reshape(-1))
 
 
+def test_matmul_single_limb_beyond_16320_terms_on_the_matrix_cores(cpa, tuning):
+    """k > 16320 is more than the int32 accumulators of k_matmul_mfma_1limb hold: with the workspace such a product runs
+    through the limb kernel with one limb (k in parts of 255 k-steps, and split over work items where the tiles are few)
+    instead of the VALU kernel; == oracle == VALU kernel, on uniform elements and on the largest signed digits."""
+    rnd = random.Random(99)
+    for name in ("goldilocks", "p64_ref_tests"):
+        g = load_golden(name)
+        p = h2i(g["modulus"])
+        f, o = field_of(cpa, g), oracle_of(g)
+        edge = [0, 1, p - 1, p - 2, 0x7F7F7F7F7F7F7F7F % p, 0x7F7F7F7F7F7F7F80 % p, (p + 0x7F7F7F7F7F7F7F7F) % p,
+                (p - 0x8080808080808080) % p, 0x8080808080808080 % p, p >> 1]
+        from soak_inversion_plans import rand_elems
+        rng = np.random.default_rng(p % 1000)
+        earr = np.array(edge, dtype=np.uint64)
+        for m, k, n in ((200, 16400, 210), (300, 2 * 16320 + 77, 250)):
+            for mode in ("uniform", "edge"):
+                if mode == "uniform":
+                    A, B = rand_elems(rng, m * k, 1, p), rand_elems(rng, k * n, 1, p)
+                else:
+                    A = earr[rng.integers(0, len(edge), size=m * k)].reshape(m * k, 1)
+                    B = earr[rng.integers(0, len(edge), size=k * n)].reshape(k * n, 1)
+                nb = f.matmul_workspace_bytes(m, k, n)
+                assert nb >= 8 * (m * k + k * n), (m, k, n, nb)
+                got = _dev_matmul(cpa, f, A, B, m, k, n, True).reshape(m * n, 1)
+                for r0 in (0, m - 2):
+                    want = o.matmul(A[r0 * k:(r0 + 2) * k], B, 2, k, n, threads=0)
+                    assert np.array_equal(got[r0 * n:(r0 + 2) * n], want.reshape(2 * n, 1)), (name, m, k, n, mode, r0)
+                assert np.array_equal(got, _dev_matmul(cpa, f, A, B, m, k, n, False).reshape(m * n, 1)), (name, m, k, n, mode, "vs VALU")
+    # a non-canonical input with no digit form: the VALU kernel answers (as for k <= 16320)
+    p = 2**61 - 1
+    f = cpa.MontyField(p, 1)
+    m, k, n = 200, 16400, 210
+    A, B = rand_elems(rng, m * k, 1, p), rand_elems(rng, k * n, 1, p)
+    A[7, 0] = np.uint64(2**64 - 1)
+    assert np.array_equal(_dev_matmul(cpa, f, A, B, m, k, n, True), _dev_matmul(cpa, f, A, B, m, k, n, False))
+
+
 _MFL_MODULI = [("bn254", 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001, 4),
                ("bls12_381", 0x1A0111EA397FE69A4B1BA7B6434BACD764774B84F38512BF6730D2A0F6B0F6241EABFFFEB153FFFFB9FEFFFFFFFFAAAB, 6),
                ("p127 in two words", 2**127 - 1, 2), ("p192", 2**192 - 2**64 - 1, 3), ("secp256k1 (tight)", 2**256 - 2**32 - 977, 4),

@@ -41,8 +41,10 @@ def test_multi_limb_matmul_workspace_follows_the_plan(tuning, n64, p):
     assert f.matmul_workspace_bytes(17, 33, 19) >= _planes(n64, 17, 33, 19)
 
 
-def test_single_limb_matmul_workspace_unchanged():
+def test_single_limb_matmul_workspace():
     import crypto_primitives_amd as cpa
     f = cpa.MontyField(cpa.GOLDILOCKS, 1)
     assert f.matmul_workspace_bytes(8192, 8192, 8192) == 256 + 2 * 8192 * 8192 * 8
-    assert f.matmul_workspace_bytes(1000, 20000, 1000) == 0        # k beyond the int32 accumulators' 16320: VALU kernel
+    # k beyond the int32 accumulators' 16320: the limb kernel with one limb (planes of both operands + scratch)
+    b = f.matmul_workspace_bytes(1000, 20000, 1000)
+    assert _planes(1, 1000, 20000, 1000) + 256 <= b <= _planes(1, 1000, 20000, 1000) + 256 + 256 * 6 * 4096 * 4

@@ -10,7 +10,10 @@ rely on are re-checked on the disassembly of every translation unit after each b
      v_readfirstlane) and a VALU instruction that reads it (carry-in, SGPR data operand).  An
      instruction in between is one wait state, `s_nop N` is N + 1.  A modulus limb materialised with
      v_readfirstlane right before the asm that multiplies by it would silently read a stale SGPR.
-  2. No v_accvgpr_* between the first and the last MFMA of k_matmul_mfma_1limb: an accumulator copied
+  3. After the last MFMA of those kernels no accumulator is read or copied before the MFMA's result latency has
+     passed (the compiler may hoist its v_accvgpr_read above a bare `s_nop` asm: found on k_matmul_mfma_limbs<2>,
+     where one output in sixteen came out wrong).
+  2. No v_accvgpr_* between the first and the last MFMA of k_matmul_mfma_1limb / k_matmul_mfma_limbs: an accumulator copied
      between asm MFMA statements would get no MFMA-write hazard padding (and means the "+a" pinning
      of the accumulators failed).
 
@@ -117,11 +120,52 @@ def check_sgpr_hazard(name, body):
     return bad
 
 
+def mfma_accumulators(body):
+    """AGPR numbers that some MFMA of the function writes (the accumulators; the compiler may also park spilled VGPRs in
+    the AGPRs left over, and moving those is no hazard)."""
+    regs = set()
+    for ins in body:
+        if ins.startswith("v_mfma"):
+            m = re.match(r"v_mfma\S*\s+a\[(\d+):(\d+)\]", ins)
+            if m:
+                regs.update(range(int(m.group(1)), int(m.group(2)) + 1))
+    return regs
+
+
+def touches(ins, regs):
+    return any(int(r) in regs for r in re.findall(r"\ba(\d+)\b", ins))
+
+
 def check_mfma_region(name, body):
     idx = [i for i, ins in enumerate(body) if ins.startswith("v_mfma")]
     if not idx:
         return []
-    return [(name, ins) for ins in body[idx[0]:idx[-1] + 1] if ins.startswith("v_accvgpr")]
+    regs = mfma_accumulators(body)
+    return [(name, ins) for ins in body[idx[0]:idx[-1] + 1] if ins.startswith("v_accvgpr") and touches(ins, regs)]
+
+
+MFMA_READ_WAIT = 18   # wait states between an MFMA's issue and a VALU read of its result registers (8-pass int8 MFMA: 18)
+
+
+def check_mfma_tail(name, body):
+    """The asm MFMAs' writes are invisible to the hazard recogniser: after the LAST one, an accumulator must not be read or
+    copied (v_accvgpr_read / v_accvgpr_mov) before MFMA_READ_WAIT wait states have passed.  Scans forward in address
+    order, which is execution order up to the first unconditional branch (where the scan stops)."""
+    idx = [i for i, ins in enumerate(body) if ins.startswith("v_mfma")]
+    if not idx:
+        return []
+    waited = 0
+    regs = mfma_accumulators(body)
+    for ins in body[idx[-1] + 1:]:
+        mnem = ins.split()[0]
+        if mnem in ("s_branch", "s_endpgm", "s_setpc_b64"):
+            break
+        if mnem in ("v_accvgpr_read_b32", "v_accvgpr_mov_b32") and waited < MFMA_READ_WAIT and touches(ins, regs):
+            return [(name, ins, waited)]
+        waited += int(ins.split()[1], 0) + 1 if mnem == "s_nop" else 1
+        if waited >= MFMA_READ_WAIT:
+            break
+    return []
 
 
 def main(argv):
@@ -131,22 +175,26 @@ def main(argv):
         print("isa_hazard_check: no objects (build the library first)")
         return 2
     total_fn = total_ins = 0
-    hazards, acc = [], []
+    hazards, acc, tail = [], [], []
     with tempfile.TemporaryDirectory() as tmp:
         for obj in objs:
             for name, body in functions(disassemble(obj, tmp)):
                 total_fn += 1
                 total_ins += len(body)
                 hazards += check_sgpr_hazard(name, body)
-                if "k_matmul_mfma_1limb" in name:
+                if "k_matmul_mfma" in name:
                     acc += check_mfma_region(name, body)
+                    tail += check_mfma_tail(name, body)
     for name, w, r, age in hazards[:40]:
         print(f"HAZARD {name}: `{w}` then `{r}` after {age} wait state(s)")
     for name, ins in acc[:40]:
         print(f"ACCVGPR inside the MFMA stream of {name}: `{ins}`")
+    for name, ins, waited in tail[:40]:
+        print(f"MFMA RESULT READ TOO EARLY in {name}: `{ins}` {waited} wait state(s) after the last MFMA")
     print(f"isa_hazard_check: {len(objs)} objects, {total_fn} kernels, {total_ins} instructions, "
-          f"{len(hazards)} SGPR hazards, {len(acc)} accvgpr moves inside the MFMA stream")
-    return 1 if hazards or acc else 0
+          f"{len(hazards)} SGPR hazards, {len(acc)} accvgpr moves inside the MFMA stream, "
+          f"{len(tail)} accumulator reads within {MFMA_READ_WAIT} wait states of the last MFMA")
+    return 1 if hazards or acc or tail else 0
 
 
 if __name__ == "__main__":
