@@ -215,8 +215,9 @@ int fpgpu_spmv_dev(const fpgpu_ctx *ctx, const void *vals, const uint32_t *col_i
                    size_t density, const void *x, void *y, void *stream);
 /* C[i*n + j] = sum_l mul(A[i*k + l], B[l*n + j]); A is m x k, B is k x n, C is m x n.
  * `workspace` is optional device scratch (256-byte aligned) of at least
- * fpgpu_matmul_workspace_bytes(ctx, m, k, n) bytes; with it, single-limb fields (n64 == 1,
- * k <= 16320) run on the matrix cores (int8 digit planes of A and B^T live there), and so do
+ * fpgpu_matmul_workspace_bytes(ctx, m, k, n) bytes; with it, single-limb fields (n64 == 1)
+ * run on the matrix cores (int8 digit planes of A and B^T live there; any k: beyond 16320 terms
+ * in parts, 1024 x 32768 x 1024 in 1.8 ms against 10.0), and so do
  * multi-limb fields (n64 = 2 ... 8, any k) from about 256 x 1024 x 256 on, as n64 x n64
  * single-limb products (digit planes of every limb plus up to 256 x (2 n64 - 1) x 96 KiB of scratch:
  * 232 MiB for 1024^3 at 256 bits, 3.4 against 0.87 ms; products of few output tiles split k over
