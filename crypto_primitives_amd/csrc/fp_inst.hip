@@ -278,13 +278,15 @@ hipError_t Launch<N>::matmul(const fpgpu_ctx* ctx, const void* A, const void* B,
         if (tune.matmul_generic <= 0) {
             const size_t gx = (n + kMM1_BN - 1) / kMM1_BN, gy = (m + kMM1_BM - 1) / kMM1_BM;
             const MfmaPlan pl = make_mfma_plan(ctx->n64, m, k, n);
-            const bool mfma = pl.usable && workspace && workspace_bytes >= pl.bytes && tune.matmul_mfma != 0;
+            // k beyond the int32 accumulators of k_matmul_mfma_1limb, or too few tiles for the chip: the limb kernel with one
+            // limb (k in parts of 255 k-steps, k split over work items where the tiles are few), the VALU kernel behind its flag
+            MflPlan ml = make_mfl_plan(ctx->n64, m, k, n, pl.usable || tune.matmul_mfma > 0);
+            if (pl.usable && !one_limb_takes_limb_kernel(pl, ml)) ml = MflPlan{};
+            const bool limbs = ml.usable && workspace && workspace_bytes >= ml.bytes && tune.matmul_mfma != 0;
+            const bool mfma = !limbs && pl.usable && workspace && workspace_bytes >= pl.bytes && tune.matmul_mfma != 0;
             if (!mfma) {
-                // k beyond the int32 accumulators of k_matmul_mfma_1limb: the limb kernel with one limb (k in parts of 255
-                // k-steps, k split over work items where the tiles are few), the VALU kernel behind its flag
                 const uint32_t* gate1 = nullptr;
-                const MflPlan ml = pl.usable ? MflPlan{} : make_mfl_plan(ctx->n64, m, k, n, tune.matmul_mfma > 0);
-                if (ml.usable && workspace && workspace_bytes >= ml.bytes && tune.matmul_mfma != 0) {
+                if (limbs) {
                     uint8_t* ws = (uint8_t*)workspace;
                     uint32_t* flag = (uint32_t*)ws;
                     if (hipError_t e = hipMemsetAsync(flag, 0, 4, s); e != hipSuccess) return e;

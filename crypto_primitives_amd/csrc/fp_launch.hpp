@@ -224,6 +224,15 @@ inline MflPlan make_mfl_plan(uint32_t n64, size_t m, size_t k, size_t n, bool fo
     pl.bytes = pl.p_off + (z > 1 ? ((m * n * z * 8 * n64 + 255) / 256) * 256 : 0);
     return pl;
 }
+// Single-limb products k_matmul_mfma_1limb can take (k <= 16320) but whose 64 x 64 tiles are too few for the chip: the limb
+// kernel with one limb splits k over work items (256 x 8192 x 256 Goldilocks: 16 tiles, 128 k-steps each on 16 CUs).  Taken
+// when its model time (a work item's k-steps at 3.0 us + its epilogue, + the combine) is under 0.7 of the single-limb
+// kernel's (a tile's k-steps at 2.6 us).
+inline bool one_limb_takes_limb_kernel(const MfmaPlan& pl, const MflPlan& ml) {
+    if (!pl.usable || !ml.usable || ml.zparts < 2) return false;
+    const double t1 = (double)pl.ksteps * 2.6, tl = (double)ml.zsteps * 3.0 + 5.0 + 10.0;
+    return tl < 0.7 * t1;
+}
 constexpr int kFoldBlocks = 2048;  // partials of the first fold pass (workspace = kFoldBlocks elements)
 int grid_for(size_t n);
 

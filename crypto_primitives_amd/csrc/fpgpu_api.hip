@@ -466,9 +466,10 @@ size_t fpgpu_matmul_workspace_bytes(const fpgpu_ctx* ctx, size_t m, size_t k, si
         return ml.usable && tuning().matmul_mfma != 0 ? ml.bytes : 0;
     }
     const MfmaPlan pl = make_mfma_plan(ctx->n64, m, k, n);
-    if (pl.usable) return pl.bytes;
-    // a single-limb product with k beyond the int32 accumulators: the limb kernel's planes and scratch
-    const MflPlan ml = make_mfl_plan(ctx->n64, m, k, n, tuning().matmul_mfma > 0);
+    // a single-limb product with k beyond the int32 accumulators, or with too few tiles for the chip: the limb kernel's planes
+    // and scratch (never less than the single-limb kernel's planes: a caller may still force that one)
+    const MflPlan ml = make_mfl_plan(ctx->n64, m, k, n, pl.usable || tuning().matmul_mfma > 0);
+    if (pl.usable) return one_limb_takes_limb_kernel(pl, ml) && ml.bytes > pl.bytes ? ml.bytes : pl.bytes;
     return ml.usable && tuning().matmul_mfma != 0 ? ml.bytes : 0;
 }
 

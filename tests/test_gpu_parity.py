@@ -532,6 +532,21 @@ def test_matmul_single_limb_beyond_16320_terms_on_the_matrix_cores(cpa, tuning):
                     want = o.matmul(A[r0 * k:(r0 + 2) * k], B, 2, k, n, threads=0)
                     assert np.array_equal(got[r0 * n:(r0 + 2) * n], want.reshape(2 * n, 1)), (name, m, k, n, mode, r0)
                 assert np.array_equal(got, _dev_matmul(cpa, f, A, B, m, k, n, False).reshape(m * n, 1)), (name, m, k, n, mode, "vs VALU")
+    # every digit product at its extreme over the longest run the int32 accumulators take, in BOTH matrix-core kernels at
+    # full occupancy (225 tiles: no k split): k = 16320 is the single-limb kernel's bound, k = 16384 the limb kernel's
+    # first k part of 255 k-steps plus one more
+    g = load_golden("goldilocks")
+    p = h2i(g["modulus"])
+    f, o = field_of(cpa, g), oracle_of(g)
+    m = n = 900
+    for k in (16320, 16384):
+        for va, vb in ((0x7F7F7F7F7F7F7F7F, 0x7F7F7F7F7F7F7F7F), (0x7F7F7F7F7F7F7F80, 0x7F7F7F7F7F7F7F80), (0x7F7F7F7F7F7F7F7F, 0x7F7F7F7F7F7F7F80)):
+            A = np.full((m * k, 1), va % p, dtype=np.uint64)
+            B = np.full((k * n, 1), vb % p, dtype=np.uint64)
+            got = _dev_matmul(cpa, f, A, B, m, k, n, True).reshape(m * n, 1)
+            want = o.matmul(A[:2 * k], B, 2, k, n, threads=0).reshape(2 * n, 1)
+            assert np.array_equal(got[:2 * n], want) and np.array_equal(got[-2 * n:], want), (k, hex(va), hex(vb))
+            assert (got == got[0]).all(), (k, hex(va), hex(vb))      # constant operands: every output is the same residue
     # a non-canonical input with no digit form: the VALU kernel answers (as for k <= 16320)
     p = 2**61 - 1
     f = cpa.MontyField(p, 1)
