@@ -234,6 +234,33 @@ hipError_t Launch<N>::matvec(const fpgpu_ctx* ctx, const void* A, size_t rows, s
     return hipSuccess;
 }
 
+// The limb kernel's launches (fp_matmul_mfma_limbs.cuh) over a workspace laid out by make_mfl_plan: the flag word first (it
+// stays the caller's gate for the VALU fallback), the digitisers of A and B^T (one limb per blockIdx.y), the product, and
+// the sum of the k parts where the plan split k over work items (it sums whatever the scratch holds when the flag is up:
+// the gated VALU kernel then overwrites C).
+template <int N>
+static hipError_t launch_limb_matmul(const fpgpu_ctx* ctx, const MflPlan& pl, const void* A, const void* B, void* C, size_t m,
+                                     size_t k, size_t n, void* workspace, hipStream_t s) {
+    uint8_t* ws = (uint8_t*)workspace;
+    uint32_t* flag = (uint32_t*)ws;
+    if (hipError_t e = hipMemsetAsync(flag, 0, 4, s); e != hipSuccess) return e;
+    const unsigned wa = pl.rblocks * pl.ksteps, wb = pl.cblocks * pl.ksteps;  // x4 waves = one workgroup each
+    hipLaunchKernelGGL((k_mfl_digitize<N, false>), dim3(wa, N / 2), dim3(256), 0, s, (const uint32_t*)A, m, k, k, ws + pl.a_off,
+                       pl.plane_a, pl.rblocks, pl.ksteps, flag, make_params<N>(ctx));
+    hipLaunchKernelGGL((k_mfl_digitize<N, true>), dim3(wb, N / 2), dim3(256), 0, s, (const uint32_t*)B, n, k, n, ws + pl.b_off,
+                       pl.plane_b, pl.cblocks, pl.ksteps, flag, make_params<N>(ctx));
+    uint32_t* dst = pl.zparts > 1 ? (uint32_t*)(ws + pl.p_off) : (uint32_t*)C;
+    hipLaunchKernelGGL((k_matmul_mfma_limbs<N>), dim3(pl.grid), dim3(256), 0, s, ws + pl.a_off, ws + pl.b_off, pl.plane_a,
+                       pl.plane_b, dst, m, n, pl.rblocks, pl.cblocks, pl.ksteps, pl.zparts, pl.zsteps,
+                       (uint32_t*)(ws + pl.t_off), (const uint32_t*)flag, make_params<N>(ctx));
+    if (pl.zparts > 1) {
+        const size_t outs = m * n, cw = (outs + kBlock / 64 - 1) / (kBlock / 64);
+        hipLaunchKernelGGL((k_matvec_combine<N>), dim3((unsigned)cw), dim3(kBlock), 0, s, (const uint32_t*)dst, (uint32_t*)C, outs,
+                           pl.zparts, make_params<N>(ctx));
+    }
+    return hipSuccess;
+}
+
 template <int N>
 hipError_t Launch<N>::matmul(const fpgpu_ctx* ctx, const void* A, const void* B, void* C, size_t m, size_t k, size_t n,
                        void* workspace, size_t workspace_bytes, hipStream_t s) {
@@ -287,23 +314,8 @@ hipError_t Launch<N>::matmul(const fpgpu_ctx* ctx, const void* A, const void* B,
             if (!mfma) {
                 const uint32_t* gate1 = nullptr;
                 if (limbs) {
-                    uint8_t* ws = (uint8_t*)workspace;
-                    uint32_t* flag = (uint32_t*)ws;
-                    if (hipError_t e = hipMemsetAsync(flag, 0, 4, s); e != hipSuccess) return e;
-                    hipLaunchKernelGGL((k_mfl_digitize<N, false>), dim3(ml.rblocks * ml.ksteps, 1), dim3(256), 0, s, (const uint32_t*)A, m,
-                                       k, k, ws + ml.a_off, ml.plane_a, ml.rblocks, ml.ksteps, flag, make_params<N>(ctx));
-                    hipLaunchKernelGGL((k_mfl_digitize<N, true>), dim3(ml.cblocks * ml.ksteps, 1), dim3(256), 0, s, (const uint32_t*)B, n,
-                                       k, n, ws + ml.b_off, ml.plane_b, ml.cblocks, ml.ksteps, flag, make_params<N>(ctx));
-                    uint32_t* dst = ml.zparts > 1 ? (uint32_t*)(ws + ml.p_off) : (uint32_t*)C;
-                    hipLaunchKernelGGL((k_matmul_mfma_limbs<N>), dim3(ml.grid), dim3(256), 0, s, ws + ml.a_off, ws + ml.b_off,
-                                       ml.plane_a, ml.plane_b, dst, m, n, ml.rblocks, ml.cblocks, ml.ksteps, ml.zparts, ml.zsteps,
-                                       (uint32_t*)(ws + ml.t_off), (const uint32_t*)flag, make_params<N>(ctx));
-                    if (ml.zparts > 1) {
-                        const size_t outs = m * n, cw = (outs + kBlock / 64 - 1) / (kBlock / 64);
-                        hipLaunchKernelGGL((k_matvec_combine<N>), dim3((unsigned)cw), dim3(kBlock), 0, s, (const uint32_t*)dst,
-                                           (uint32_t*)C, outs, ml.zparts, make_params<N>(ctx));
-                    }
-                    gate1 = flag;
+                    if (hipError_t e = launch_limb_matmul<N>(ctx, ml, A, B, C, m, k, n, workspace, s); e != hipSuccess) return e;
+                    gate1 = (const uint32_t*)workspace;
                 }
                 hipLaunchKernelGGL((k_matmul_1limb<N>), dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, s,
                                    (const uint2*)A, (const uint2*)B, (uint2*)C, m, k, n, gate1, make_params<N>(ctx));
@@ -337,24 +349,8 @@ hipError_t Launch<N>::matmul(const fpgpu_ctx* ctx, const void* A, const void* B,
         const Tuning& tune = tuning();
         const MflPlan pl = make_mfl_plan(ctx->n64, m, k, n, tune.matmul_mfma > 0);
         if (pl.usable && workspace && workspace_bytes >= pl.bytes && tune.matmul_mfma != 0 && tune.matmul_generic <= 0) {
-            uint8_t* ws = (uint8_t*)workspace;
-            uint32_t* flag = (uint32_t*)ws;
-            if (hipError_t e = hipMemsetAsync(flag, 0, 4, s); e != hipSuccess) return e;
-            const unsigned wa = pl.rblocks * pl.ksteps, wb = pl.cblocks * pl.ksteps;  // x4 waves = one workgroup each
-            hipLaunchKernelGGL((k_mfl_digitize<N, false>), dim3(wa, N / 2), dim3(256), 0, s, (const uint32_t*)A, m, k, k,
-                               ws + pl.a_off, pl.plane_a, pl.rblocks, pl.ksteps, flag, make_params<N>(ctx));
-            hipLaunchKernelGGL((k_mfl_digitize<N, true>), dim3(wb, N / 2), dim3(256), 0, s, (const uint32_t*)B, n, k, n,
-                               ws + pl.b_off, pl.plane_b, pl.cblocks, pl.ksteps, flag, make_params<N>(ctx));
-            uint32_t* dst = pl.zparts > 1 ? (uint32_t*)(ws + pl.p_off) : (uint32_t*)C;
-            hipLaunchKernelGGL((k_matmul_mfma_limbs<N>), dim3(pl.grid), dim3(256), 0, s, ws + pl.a_off, ws + pl.b_off,
-                               pl.plane_a, pl.plane_b, dst, m, n, pl.rblocks, pl.cblocks, pl.ksteps, pl.zparts, pl.zsteps,
-                               (uint32_t*)(ws + pl.t_off), (const uint32_t*)flag, make_params<N>(ctx));
-            if (pl.zparts > 1) {   // (sums whatever the scratch holds when the flag is up: k_matmul below then overwrites C)
-                const size_t outs = m * n, cw = (outs + kBlock / 64 - 1) / (kBlock / 64);
-                hipLaunchKernelGGL((k_matvec_combine<N>), dim3((unsigned)cw), dim3(kBlock), 0, s, (const uint32_t*)dst,
-                                   (uint32_t*)C, outs, pl.zparts, make_params<N>(ctx));
-            }
-            gate = flag;   // the VALU kernel below then runs only if some input had no digit form
+            if (hipError_t e = launch_limb_matmul<N>(ctx, pl, A, B, C, m, k, n, workspace, s); e != hipSuccess) return e;
+            gate = (const uint32_t*)workspace;   // the flag: the VALU kernel below then runs only if some input had no digit form
         }
     }
 #endif

@@ -202,3 +202,39 @@ def test_graph_replay_of_a_launch_bound_chain(cpa):
         times[label] = (time.perf_counter() - t0) / 20 * 1e6
         assert np.array_equal(_host(u, 4), want), label
     print("85 launches on 4096 elements: direct %.0f us, graph replay %.0f us" % (times["direct"], times["graph"]))
+
+
+@pytest.mark.parametrize("name,p,n64,shape", [("bn254: limb kernel, k split over work items", None, 4, (70, 300, 66)),
+                                              ("bls12_381: limb kernel", 0x1A0111EA397FE69A4B1BA7B6434BACD764774B84F38512BF6730D2A0F6B0F6241EABFFFEB153FFFFB9FEFFFFFFFFAAAB, 6, (65, 130, 64)),
+                                              ("goldilocks: single-limb kernel", 2**64 - 2**32 + 1, 1, (70, 130, 66)),
+                                              ("goldilocks: limb kernel with one limb (few tiles, long k)", 2**64 - 2**32 + 1, 1, (200, 2100, 210))])
+def test_matrix_core_matmul_records_into_a_hip_graph(cpa, tuning, name, p, n64, shape):
+    """fpgpu_matmul_dev with its workspace (digitisers, the matrix-core kernel, the combine of k parts, the gated VALU
+    fallback, one hipMemsetAsync of the flag) is captured once and replayed on new operands; == oracle."""
+    import torch
+    from oracle.fp_oracle import Oracle
+    from soak_inversion_plans import rand_elems
+    p = p or cpa.BN254_FR
+    f, o = cpa.MontyField(p, n64), Oracle(p, n64)
+    if n64 > 1:
+        tuning("FPGPU_MATMUL_MFMA", 1)            # (small shapes: the plan alone would leave them to the VALU kernel)
+    m, k, n = shape
+    rng = np.random.default_rng(n64)
+    A, B, C = f.alloc(m * k), f.alloc(k * n), f.alloc(m * n)
+    nb = f.matmul_workspace_bytes(m, k, n)
+    assert nb > 0
+    ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    hA, hB = rand_elems(rng, m * k, n64, p), rand_elems(rng, k * n, n64, p)
+    A.copy_(_dev(torch, hA)); B.copy_(_dev(torch, hB))
+    f.matmul_dev(A, B, C, m, k, n, workspace=ws)    # outside capture first: code objects load on first use
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        f.matmul_dev(A, B, C, m, k, n, workspace=ws)
+    for _ in range(2):
+        hA, hB = rand_elems(rng, m * k, n64, p), rand_elems(rng, k * n, n64, p)
+        A.copy_(_dev(torch, hA)); B.copy_(_dev(torch, hB))
+        C.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert np.array_equal(_host(C, n64), o.matmul(hA, hB, m, k, n, threads=0).reshape(m * n, n64))
