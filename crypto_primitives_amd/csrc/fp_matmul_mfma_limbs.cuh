@@ -9,7 +9,8 @@
 // so the product is NL^2 passes of the SAME main loop (fp_matmul_kstep.inc, untouched) over digit planes of limb u
 // of A and limb v of B^T -- 64 NL^2 int8 multiply-accumulates per term, the minimum for byte digits -- and the
 // pairs of one limb diagonal w share their int32 accumulators (same weights), which are exact while the k-steps a
-// diagonal has absorbed stay <= 255: k is walked in parts of floor(255 / NL) k-steps.  After each (k part, w) the
+// diagonal has absorbed stay <= 255: k is walked in parts of floor(255 / NL) k-steps.  The k-steps of all diagonals and
+// parts of a tile form ONE stream, staged one step ahead of the MFMAs across their boundaries.  After each (k part, w) the
 // 15 digit diagonals are recombined into a 192-bit two's-complement value T_w per output and added into the
 // workgroup's scratch (6 words per w per output, plain stores by the lane that owns the output: no atomics, the
 // scratch belongs to the workgroup, which walks tiles persistently).  A tile ends with V = sum_w T_w 2^(64 w),
@@ -143,24 +144,31 @@ __global__ __launch_bounds__(256) void k_matmul_mfma_limbs(const uint8_t* __rest
         uint32_t rb, cb;
         if (!mf_tile_of(tb, rblocks, cblocks, rb, cb)) continue;     // (uniform over the workgroup)
         const uint32_t ks_lo = z * zsteps, ks_hi = ks_lo + zsteps < ksteps ? ks_lo + zsteps : ksteps;
+        // ONE stream of k-steps per item: (k part, limb diagonal w, pair u of the diagonal, k-step of the part), staged one step
+        // ahead of the MFMAs ACROSS the diagonals and k parts -- the first chunk of the next diagonal is in flight while this
+        // one's accumulators are recombined, so only the item's first k-step waits for its data.  `gs` counts the item's
+        // k-steps (buffer parity); the cursor c_* names the step staged last.
+        uint32_t gs = 0, c_kp0 = ks_lo, c_k = 0;
+        int c_w = 0, c_u = 0;
+        auto stage_part_at = [&](uint32_t kp0s, int ws, int u, uint32_t kl, int buf, int q) {
+            const int piece = q * 4 + wave;
+            const uint8_t* ga = Aw + (size_t)u * plane_a + ((size_t)rb * ksteps + kp0s + kl) * kMF_CHUNK;
+            const uint8_t* gb = Bw + (size_t)(ws - u) * plane_b + ((size_t)cb * ksteps + kp0s + kl) * kMF_CHUNK;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ga + piece * 1024 + lane_off),
+                                             (__attribute__((address_space(3))) void*)(lds + buf * 2 * kMF_CHUNK + piece * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gb + piece * 1024 + lane_off),
+                                             (__attribute__((address_space(3))) void*)(lds + buf * 2 * kMF_CHUNK + kMF_CHUNK + piece * 1024), 16, 0, 0);
+        };
+        // (the previous item's last barrier came after every wave's last LDS read and DMA: both buffers are free)
+#pragma unroll
+        for (int q = 0; q < 8; q++) stage_part_at(c_kp0, c_w, c_u, c_k, 0, q);
+        __syncthreads();
         for (uint32_t kp0 = ks_lo; kp0 < ks_hi; kp0 += kPart) {
             const uint32_t kpn = ks_hi - kp0 < kPart ? ks_hi - kp0 : kPart;
 #pragma unroll 1
             for (int w = 0; w < NW; w++) {
                 const int u0 = w - (NL - 1) > 0 ? w - (NL - 1) : 0, u1 = w < NL - 1 ? w : NL - 1;
                 const uint32_t vsteps = (uint32_t)(u1 - u0 + 1) * kpn;
-                // the staging cursor: (pair, k-step inside the part) of the NEXT virtual k-step to stage
-                int su = u0;
-                uint32_t sk = 0;
-                auto stage_part_at = [&](int u, uint32_t kl, int buf, int q) {
-                    const int piece = q * 4 + wave;
-                    const uint8_t* ga = Aw + (size_t)u * plane_a + ((size_t)rb * ksteps + kp0 + kl) * kMF_CHUNK;
-                    const uint8_t* gb = Bw + (size_t)(w - u) * plane_b + ((size_t)cb * ksteps + kp0 + kl) * kMF_CHUNK;
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ga + piece * 1024 + lane_off),
-                                                     (__attribute__((address_space(3))) void*)(lds + buf * 2 * kMF_CHUNK + piece * 1024), 16, 0, 0);
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gb + piece * 1024 + lane_off),
-                                                     (__attribute__((address_space(3))) void*)(lds + buf * 2 * kMF_CHUNK + kMF_CHUNK + piece * 1024), 16, 0, 0);
-                };
                 mf_v4i acc[15][2][2];
 #pragma unroll
                 for (int d = 0; d < 15; d++)
@@ -168,26 +176,33 @@ __global__ __launch_bounds__(256) void k_matmul_mfma_limbs(const uint8_t* __rest
                     for (int rt = 0; rt < 2; rt++)
 #pragma unroll
                         for (int ct = 0; ct < 2; ct++) acc[d][rt][ct] = mf_v4i{0, 0, 0, 0};
-                __syncthreads();   // every wave is done with both LDS buffers (previous pass)
-#pragma unroll
-                for (int q = 0; q < 8; q++) stage_part_at(su, sk, 0, q);
-                __syncthreads();
-                for (uint32_t ks = 0; ks < vsteps; ks++) {
-                    // advance the cursor to virtual k-step ks + 1 (the last one re-stages itself into the idle buffer)
-                    if (ks + 1 < vsteps) {
-                        if (++sk == kpn) { sk = 0; su++; }
+                for (uint32_t ks = 0; ks < vsteps; ks++, gs++) {
+                    // the cursor moves to the step after the one computed now; past the item's end it stays (the last step
+                    // re-stages itself into the idle buffer, so that no branch surrounds the DMAs)
+                    {
+                        uint32_t n_kp0 = c_kp0, n_k = c_k + 1;
+                        int n_w = c_w, n_u = c_u;
+                        const uint32_t c_kpn = ks_hi - c_kp0 < kPart ? ks_hi - c_kp0 : kPart;
+                        if (n_k == c_kpn) {
+                            n_k = 0;
+                            if (++n_u > (n_w < NL - 1 ? n_w : NL - 1)) {
+                                if (++n_w == NW) { n_w = 0; n_kp0 += kPart; }
+                                n_u = n_w - (NL - 1) > 0 ? n_w - (NL - 1) : 0;
+                            }
+                        }
+                        if (n_kp0 < ks_hi) { c_kp0 = n_kp0; c_k = n_k; c_w = n_w; c_u = n_u; }
                     }
-                    const int nu = su;
-                    const uint32_t nk = sk;
+                    const uint32_t s_kp0 = c_kp0, s_k = c_k;
+                    const int s_w = c_w, s_u = c_u;
                     mf_v4i a[2][8], b[2][2];
-                    const uint32_t a_addr = lds_addr + (ks & 1) * 2 * kMF_CHUNK + lane_off + 2 * wr * 1024;
-                    const uint32_t b_addr = lds_addr + (ks & 1) * 2 * kMF_CHUNK + kMF_CHUNK + lane_off + 2 * wc * 1024;
+                    const uint32_t a_addr = lds_addr + (gs & 1) * 2 * kMF_CHUNK + lane_off + 2 * wr * 1024;
+                    const uint32_t b_addr = lds_addr + (gs & 1) * 2 * kMF_CHUNK + kMF_CHUNK + lane_off + 2 * wc * 1024;
 #pragma push_macro("MF_STAGE")
 #undef MF_STAGE
-#define MF_STAGE(J) stage_part_at(nu, nk, (ks + 1) & 1, J)
+#define MF_STAGE(J) stage_part_at(s_kp0, s_w, s_u, s_k, (gs + 1) & 1, J)
 #include "fp_matmul_kstep.inc"
 #pragma pop_macro("MF_STAGE")
-                    __syncthreads();
+                    __syncthreads();   // the next step's chunk has landed (vmcnt(0) per wave) and this buffer is free to refill
                 }
                 asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // MFMA write -> accvgpr read, invisible to the compiler
                 MF_FENCE_ACC(acc);
