@@ -49,6 +49,9 @@ def test_batch_inversion_is_reported_against_the_valu_roofline():
     assert "valu_kernel_ms_for_comparison" not in d["extra"]["matmul_goldilocks"]      # timed live now
     assert d["extra"]["matmul_goldilocks"]["valu_kernel_ms_same_run"] > 50
     assert "bf16" in d["extra"]["matmul_goldilocks"]["int8_peak_note"]      # the int8 peak is priced from the guide's bf16 figure
+    mm = d["extra"]["matmul_bn254"]                                         # multi-limb product on the matrix cores beside the VALU kernel
+    assert mm["same_bits_as_valu_kernel"] is True and mm["ms_per_matmul"] < mm["valu_kernel_ms_same_run"]
+    assert abs(mm["mfma_frac"] - 2 * 64 * 16 * mm["dim"] ** 3 / (mm["ms_per_matmul"] * 1e-3) / 1e12 / mm["int8_mfma_peak_Tops"]) < 1e-9
 
 
 def test_bare_multi_gpu_invocation_spawns_its_ranks():
