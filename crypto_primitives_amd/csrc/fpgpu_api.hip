@@ -753,8 +753,11 @@ int fpgpu_matvec(const fpgpu_ctx* ctx, const uint64_t* A, size_t rows, size_t co
         CHECK(upload_staged(dx.p, x, cols * esz, nullptr));
     }
     DevBuf ws;
-    const size_t ws_bytes = fpgpu_matvec_workspace_bytes(ctx, rows, cols);
-    if (ws_bytes) CHECK(ws.alloc(ws_bytes));
+    size_t ws_bytes = fpgpu_matvec_workspace_bytes(ctx, rows, cols);
+    if (ws_bytes && ws.alloc(ws_bytes) != FPGPU_OK) {   // optional: without it the VALU kernels run
+        ws_bytes = 0;
+        (void)hipGetLastError();
+    }
     CHECK(fpgpu_matvec_dev(ctx, dA.p, rows, cols, dx.p, dy.p, ws_bytes ? ws.p : nullptr, ws_bytes, nullptr));
     HIP_TRY(hipStreamSynchronize(nullptr));
     CHECK(download_staged(y, dy.p, rows * esz, nullptr));
@@ -804,8 +807,11 @@ int fpgpu_matmul(const fpgpu_ctx* ctx, const uint64_t* A, const uint64_t* B, uin
         CHECK(upload_staged(dB.p, B, k * n * esz, nullptr));
     }
     DevBuf ws;
-    const size_t ws_bytes = fpgpu_matmul_workspace_bytes(ctx, m, k, n);
-    if (ws_bytes) CHECK(ws.alloc(ws_bytes));
+    size_t ws_bytes = fpgpu_matmul_workspace_bytes(ctx, m, k, n);
+    if (ws_bytes && ws.alloc(ws_bytes) != FPGPU_OK) {   // the workspace is optional (it can be gigabytes): without it the VALU kernels run
+        ws_bytes = 0;
+        (void)hipGetLastError();
+    }
     CHECK(fpgpu_matmul_dev(ctx, dA.p, dB.p, dC.p, m, k, n, ws_bytes ? ws.p : nullptr, ws_bytes, nullptr));
     HIP_TRY(hipStreamSynchronize(nullptr));
     CHECK(download_staged(C, dC.p, m * n * esz, nullptr));

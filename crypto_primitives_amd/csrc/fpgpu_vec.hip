@@ -945,8 +945,11 @@ int fpgpu_vec_matvec(const fpgpu_ctx* ctx, const fpgpu_vec* A, size_t rows, size
         if (prows == 0) return (int)FPGPU_OK;
         const char* px;
         CHECK(whole_on_slot(x, a.slot, "x", &px));
-        const size_t wsb = fpgpu_matvec_workspace_bytes(ctx, prows, cols);
-        if (wsb) CHECK(ensure_scratch(a.slot, wsb));
+        size_t wsb = fpgpu_matvec_workspace_bytes(ctx, prows, cols);
+        if (wsb && ensure_scratch(a.slot, wsb) != FPGPU_OK) {   // the workspace is optional: without it the VALU kernels run
+            wsb = 0;
+            (void)hipGetLastError();
+        }
         return fpgpu_matvec_dev(ctx, a.ptr, prows, cols, px, dst, wsb ? a.slot->scratch : nullptr, wsb, a.slot->stream);
     });
 }
@@ -962,8 +965,11 @@ int fpgpu_vec_matmul(const fpgpu_ctx* ctx, const fpgpu_vec* A, const fpgpu_vec* 
         if (prows == 0) return (int)FPGPU_OK;
         const char* pb;
         CHECK(whole_on_slot(B, a.slot, "B", &pb));
-        const size_t wsb = fpgpu_matmul_workspace_bytes(ctx, prows, k, n);
-        if (wsb) CHECK(ensure_scratch(a.slot, wsb));
+        size_t wsb = fpgpu_matmul_workspace_bytes(ctx, prows, k, n);
+        if (wsb && ensure_scratch(a.slot, wsb) != FPGPU_OK) {   // optional, and it can be gigabytes (digit planes): VALU kernels otherwise
+            wsb = 0;
+            (void)hipGetLastError();
+        }
         return fpgpu_matmul_dev(ctx, a.ptr, pb, dst, prows, k, n, wsb ? a.slot->scratch : nullptr, wsb, a.slot->stream);
     });
 }
