@@ -17,7 +17,7 @@ for tu in fpgpu_api fpgpu_vec fpgpu_stage; do
 done
 wait
 hipcc --offload-arch=gfx950 -shared -fPIC -fsanitize=$KIND -fno-gpu-sanitize -shared-libsan -o $OUT/libfpgpu.so \
-  $OUT/fpgpu_api.o $OUT/fpgpu_vec.o $OUT/fpgpu_stage.o build/obj/fp_inst_*.o -ldl -lpthread
+  $OUT/fpgpu_api.o $OUT/fpgpu_vec.o $OUT/fpgpu_stage.o $(ls build/obj/fp_inst_*.o | grep -E 'fp_inst_[0-9]+\.o$') -ldl -lpthread   # (not the variant objects of tools/build_variant.sh)
 CLANG=/opt/rocm/lib/llvm/bin/clang
 RT=$($CLANG -print-resource-dir)/lib/linux
 LINK="-L$OUT -lfpgpu -Wl,-rpath,\$ORIGIN -Wl,-rpath,/opt/rocm/lib -Wl,-rpath,$RT -Wl,--allow-shlib-undefined"
